@@ -1,0 +1,135 @@
+/* zkhip.h — C ABI of the MI355X-native Groth16 hot path (libzkhip.so).
+ *
+ * The reference (iden3/rapidsnark-old) has no FFI layer: its seam is the C++ template
+ * `Groth16::Prover<Engine>` (reference src/groth16.hpp:37-121).  This header is the
+ * C-ABI a maintainer would bind in its place; every entry point cites the reference
+ * interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Byte conventions are the reference's own:
+ *   Fr / Fq element : 32 bytes little-endian (== FrElement / 4 x u64)
+ *   G1 affine       : x|y, Montgomery form (R = 2^256), 64 bytes; all-zero = infinity
+ *   G2 affine       : x.a|x.b|y.a|y.b, Montgomery form, 128 bytes
+ *   witness         : nVars x 32 B, standard (non-Montgomery) form   (src/main_prover.cpp:74)
+ *
+ * All functions return 0 on success, non-zero on error; zk_last_error() gives the
+ * message for the calling thread.  Nothing throws across this boundary.  There is NO
+ * CPU fallback: if no HIP device is usable every call fails with an error.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_prover zk_prover;
+
+/* The 15 arguments of Groth16::makeProver<Engine>() (src/groth16.hpp:104-121,
+ * call site src/main_prover.cpp:57-73), plus section byte sizes for bounds checks. */
+typedef struct zk_zkey_view {
+    uint32_t nVars;
+    uint32_t nPublic;
+    uint32_t domainSize;
+    uint64_t nCoefs;
+    const void *vk_alpha1;   /* G1, zkey section 2 */
+    const void *vk_beta1;    /* G1 */
+    const void *vk_beta2;    /* G2 */
+    const void *vk_delta1;   /* G1 */
+    const void *vk_delta2;   /* G2 */
+    const void *coefs;       /* section 4 INCLUDING its leading u32 count (src/groth16.cpp:38 skips 4 bytes) */
+    const void *pointsA;     /* section 5: nVars x G1 */
+    const void *pointsB1;    /* section 6: nVars x G1 */
+    const void *pointsB2;    /* section 7: nVars x G2 */
+    const void *pointsC;     /* section 8: (nVars-nPublic-1) x G1 */
+    const void *pointsH;     /* section 9: domainSize x G1 */
+    uint64_t coefs_bytes, pointsA_bytes, pointsB1_bytes, pointsB2_bytes, pointsC_bytes, pointsH_bytes;
+} zk_zkey_view;
+
+typedef struct zk_opts {
+    int32_t device;          /* HIP device ordinal; -1 = current device */
+    uint32_t shard_index;    /* this prover holds shard `shard_index` of `shard_count` of every MSM   */
+    uint32_t shard_count;    /*   point table (contiguous index slices); 0 or 1 = whole    */
+    uint32_t window_bits;    /* Pippenger window c; 0 = choose from the size                           */
+    uint32_t flags;          /* ZK_FLAG_* */
+} zk_opts;
+
+#define ZK_FLAG_TIMINGS 1u   /* record per-stage hipEvent timings (zk_prover_timings) */
+
+/* Same bytes as Proof<Engine>{A,B,C} (src/groth16.hpp:13-24): affine, Montgomery LE. */
+typedef struct zk_proof {
+    uint8_t A[64];
+    uint8_t B[128];
+    uint8_t C[64];
+} zk_proof;
+
+/* The five multi-exponentiation results of src/groth16.cpp:171-204 before the final
+ * assembly, as affine Montgomery points (all-zero = infinity).  With sharding these are
+ * PARTIAL sums over this prover's slice; partial sums add up across shards. */
+typedef struct zk_msm_sums {
+    uint8_t pih[64];
+    uint8_t pi_a[64];
+    uint8_t pib1[64];
+    uint8_t pi_b[128];
+    uint8_t pi_c[64];
+} zk_msm_sums;
+
+const char *zk_last_error(void);
+int zk_device_count(int *count);
+
+/* makeProver (src/groth16.cpp:9-46) + Prover ctor (src/groth16.hpp:57-95).  One-off work:
+ * CSR build of the coefficient records, upload of the point tables and twiddle tables.
+ * The host image may be freed after this returns (the reference Prover borrows it). */
+int zk_prover_create(zk_prover **out, const zk_zkey_view *zkey, const zk_opts *opts);
+void zk_prover_destroy(zk_prover *p);
+
+/* Prover::prove (src/groth16.cpp:48-254).  wtns: nVars x 32 B standard form (host memory).
+ * r32/s32: 32-byte LE scalars replacing randombytes_buf (src/groth16.cpp:216-217); NULL
+ * draws 31 random bytes each exactly as the reference does. */
+int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out);
+/* Same with the witness already resident in device memory (HBM) on the prover's device. */
+int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out);
+
+/* Multi-GPU split of prove(): steps 1-10 (src/groth16.cpp:52-204) on this prover's shard ... */
+int zk_prove_msm_dev(zk_prover *p, const void *d_wtns, zk_msm_sums *partial);
+int zk_prove_msm(zk_prover *p, const uint8_t *wtns, zk_msm_sums *partial);
+/* ... and steps 11-13 (src/groth16.cpp:209-253) over the partial sums of all shards (host, O(1)). */
+int zk_prove_finish(zk_prover *p, const zk_msm_sums *partials, uint32_t n_partials,
+                    const uint8_t *r32, const uint8_t *s32, zk_proof *out);
+
+/* Per-stage device times of the last prove, ms (needs ZK_FLAG_TIMINGS).  Order: see ZK_T_*. */
+enum {
+    ZK_T_SPMV = 0, ZK_T_NTT, ZK_T_DIGITS_SORT, ZK_T_MSM_G1_ACCUM, ZK_T_MSM_G2_ACCUM,
+    ZK_T_MSM_REDUCE, ZK_T_TOTAL_DEVICE, ZK_T_ACCUM_LAUNCHES, ZK_T_COUNT
+};
+int zk_prover_timings(zk_prover *p, double *ms, uint32_t n);
+
+/* ---- operator-level entry points (host pointers; staged through the device) ------------- */
+/* out[i] = a[i]*b[i]*R^-1 mod r  — E.fr.mul (src/groth16.cpp:91-95). */
+int zk_fr_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n);
+/* same over Fq — E.f1.mul */
+int zk_fq_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n);
+/* In-place natural-order NTT over Fr, Montgomery in/out: inverse=0 -> FFT::fft, 1 -> FFT::ifft
+ * (incl. 1/n) (src/groth16.cpp:102,115).  n must be a power of two <= 2^28. */
+int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse);
+/* The whole a/b/c pipeline of src/groth16.cpp:88-163 on host vectors a,b (Montgomery, n each):
+ * h[i] = fromMontgomery(A(w2n^(2i+1))*B(..) - C(..)), standard form. */
+int zk_fr_abc_to_h(uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n);
+/* out = sum scalars[i]*bases[i] — Curve::multiMulByScalar (src/groth16.cpp:173,197) with
+ * scalarSize = 32; result as AFFINE Montgomery (all-zero = infinity). */
+int zk_msm_g1(uint8_t out[64], const uint8_t *bases, const uint8_t *scalars, uint64_t n);
+int zk_msm_g2(uint8_t out[128], const uint8_t *bases, const uint8_t *scalars, uint64_t n);
+
+/* ---- output formatting (src/groth16.cpp:268-301, src/main_prover.cpp:77-93) - */
+/* Compact JSON exactly as nlohmann's operator<< prints Proof::toJson(); returns needed length
+ * (excluding NUL); writes at most cap bytes incl. NUL. */
+size_t zk_proof_to_json(const zk_proof *proof, char *buf, size_t cap);
+/* public.json: ["w1",...,"wN"], or null when nPublic == 0 (reference quirk Q7). */
+size_t zk_public_to_json(const uint8_t *wtns, uint32_t nPublic, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

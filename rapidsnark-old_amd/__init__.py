@@ -1,0 +1,12 @@
+"""rapidsnark-old_amd — MI355X-native Groth16 hot path (drop-in for rapidsnark's prove()).
+
+Python side = thin ctypes binding over the C-ABI in include/zkhip.h (libzkhip.so) plus a
+mirror of the reference's binfile/zkey/wtns readers.  There is no Python/CPU compute
+fallback: if libzkhip.so is missing or HIP has no device, calls raise.
+"""
+from .binfile import BinFile, open_existing            # noqa: F401
+from .zkey import ZkeyHeader, load_zkey_header          # noqa: F401
+from .wtns import WtnsHeader, load_wtns_header          # noqa: F401
+from .lib import (ZkHipError, load_library, library_path, fr_mul_vec, fq_mul_vec, fr_ntt,   # noqa: F401
+                  fr_abc_to_h, msm_g1, msm_g2, proof_to_json, public_to_json, device_count)
+from .prover import Prover, prove_files                 # noqa: F401

@@ -1,0 +1,35 @@
+// Shared host-side plumbing of libzkhip: error reporting across the C ABI and the
+// host-tail entry points (compiled by g++ in host_tail.cpp, called from prover.hip).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+namespace zk {
+
+// thread-local message behind zk_last_error()
+void set_error(const std::string &msg);
+const char *get_error();
+
+struct HostTail {
+    // Window-sum Horner: out = sum_w 2^(c*w) * windows[w]; windows are XYZZ in device layout
+    // (G1: 4 x 32 B, G2: 4 x 64 B per point).  Result affine Montgomery (zero = infinity).
+    static void combine_windows_g1(const uint8_t *windows_xyzz, uint32_t W, uint32_t c, uint8_t out_affine[64]);
+    static void combine_windows_g2(const uint8_t *windows_xyzz, uint32_t W, uint32_t c, uint8_t out_affine[128]);
+    // out += in (affine Montgomery, zero = infinity): adds shard partial sums
+    static void add_affine_g1(uint8_t acc[64], const uint8_t in[64]);
+    static void add_affine_g2(uint8_t acc[128], const uint8_t in[128]);
+    // src/groth16.cpp:219-251 — final assembly from the five MSM results.
+    static void final_assembly(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                               const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                               const uint8_t pih[64], const uint8_t pi_a[64], const uint8_t pib1[64],
+                               const uint8_t pi_b[128], const uint8_t pi_c[64],
+                               const uint8_t r32[32], const uint8_t s32[32],
+                               uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
+    // canonical base-10 of a 32-byte LE integer
+    static std::string to_dec(const uint8_t le32[32]);
+    // de-Montgomery an Fq element and print base-10 (E.f1.toString, src/groth16.cpp:274)
+    static std::string fq_mont_to_dec(const uint8_t le32[32]);
+};
+
+}   // namespace zk

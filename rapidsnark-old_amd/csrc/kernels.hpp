@@ -1,0 +1,72 @@
+// Launchers of the gfx950 kernels (defined in ntt.hip, msm.hip, fieldops.hip).
+// All pointers are device pointers; all launches are asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "field.hpp"
+#include "curve.hpp"
+
+namespace zk {
+
+// ---------------------------------------------------------------- fieldops.hip
+void launch_fr_mul_vec(Fr *out, const Fr *a, const Fr *b, uint64_t n, hipStream_t s);
+void launch_fq_mul_vec(Fq *out, const Fq *a, const Fq *b, uint64_t n, hipStream_t s);
+
+// Sparse A.w / B.w accumulation + c = a o b  (src/groth16.cpp:56-96).
+// CSR over 2n rows: rows [0,n) are matrix A, rows [n,2n) are matrix B.
+struct CsrDev {
+    const uint32_t *rowptr;   // 2n+1
+    const uint32_t *col;      // nnz: signal index s
+    const Fr *val;            // nnz: coefficient (value*R^2 as stored in the zkey)
+};
+void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- ntt.hip
+struct NttTables {
+    uint32_t logn;       // domain size 2^logn
+    const Fr *fwd;       // w_n^k,  k < n/2   (Montgomery)
+    const Fr *inv;       // w_n^-k, k < n/2
+    const Fr *coset;     // n^-1 * w_2n^brev(p) for position p < n  (bit-reversed order)
+    const Fr *ninv;      // single element n^-1 (Montgomery)
+};
+// fill the tables (device memory already allocated: n/2, n/2, n, 1 elements)
+void launch_ntt_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s);
+// Batched in-place transforms of `batch` polynomials laid out at data + k*stride_elems.
+//  dif_inverse: natural -> bit-reversed, inverse twiddles, NO scaling
+//  dit_forward: bit-reversed -> natural, forward twiddles
+void launch_ntt_dif_inverse(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s);
+void launch_ntt_dit_forward(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s);
+// x[p] *= table[p]  (coset shift fused with 1/n, src/groth16.cpp:107-110)
+void launch_fr_scale_by_table(Fr *data, uint64_t stride_elems, uint32_t batch, const Fr *table, uint64_t n, hipStream_t s);
+// x[p] *= k ; and natural<->bit-reversed permutation (operator-level zk_fr_ntt only)
+void launch_fr_scale_const(Fr *data, const Fr *k, uint64_t n, hipStream_t s);
+void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s);
+// h[i] = fromMontgomery(a[i]*b[i] - c[i])  (src/groth16.cpp:158-163)
+void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- msm.hip
+struct MsmPlan {
+    uint32_t c;          // window bits
+    uint32_t W;          // windows = ceil(255 / c)
+    uint32_t nbuckets;   // per window = 2^(c-1)
+};
+MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits);
+
+// counts[W*nbuckets] += histogram of the signed digits of scalars[0..n)
+void launch_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
+// offsets[0..W*nbuckets] = exclusive scan(counts); offsets[W*nbuckets] = total; cursor = copy of offsets
+void launch_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total_buckets, hipStream_t s);
+// entries[cursor[bucket]++] = idx | sign<<31
+void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
+// buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min
+void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, hipStream_t s);
+void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, hipStream_t s);
+// window_sums[m*W + w] = sum_k (k+1) * buckets[m][w][k]  for n_msm bucket arrays laid back to back;
+// scratch: n_msm * W * nbuckets/REDUCE_CHUNK points
+void launch_msm_reduce_g1(G1XYZZ *window_sums, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
+void launch_msm_reduce_g2(G2XYZZ *window_sums, G2XYZZ *scratch, const G2XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
+uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p);
+
+}   // namespace zk

@@ -1,0 +1,285 @@
+// BN254-Fr radix-2 NTT for gfx950 — replaces ffiasm FFT<Fr>::fft/ifft
+// (call sites src/groth16.cpp:102,115,120,133,139,152) and the coset shift loops
+// (src/groth16.cpp:107-110,125-128,144-147).
+//
+// MI355X design (not the reference's bit-reverse + log n full sweeps over RAM):
+//   * the inverse transform runs decimation-in-frequency (natural -> bit-reversed), the
+//     forward one decimation-in-time (bit-reversed -> natural); the coset shift and 1/n
+//     are applied in bit-reversed position from one table => no permutation pass at all.
+//   * each launch covers up to 11 butterfly stages on a 64 KiB LDS tile (2048 elements,
+//     limb-plane SoA so lane-consecutive elements hit distinct banks); upper-bit passes
+//     gather 2^q-element contiguous runs (>= 256 B) so HBM accesses stay coalesced.
+//     2^22 points = 3 launches instead of 22 sweeps.
+//   * a/b/c are transformed in one launch (blockIdx.y).
+// The butterflies are Montgomery-multiply bound (VALU), see DESIGN.md.
+#include "kernels.hpp"
+
+namespace zk {
+
+#define NTT_THREADS 512
+#define NTT_MAX_TILE_LOG 11
+
+template <class F>
+__device__ __forceinline__ F load_el(const F *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 lo = q[0], hi = q[1];
+    F r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void store_el(F *p, const F &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+__device__ __forceinline__ Fr lds_get(const uint32_t *lds, uint32_t N, uint32_t e) {
+    Fr r;
+#pragma unroll
+    for (int l = 0; l < 8; l++) r.v[l] = lds[l * N + e];
+    return r;
+}
+__device__ __forceinline__ void lds_put(uint32_t *lds, uint32_t N, uint32_t e, const Fr &r) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) lds[l * N + e] = r.v[l];
+}
+
+// One pass over index bits [lo, lo+t): 2^t rows x 2^q contiguous columns per workgroup.
+//   DIF : stages from bit lo+t-1 down to lo:  (u,v) -> (u+v, (u-v)*w)
+//   DIT : stages from bit lo up to lo+t-1:    (u,v) -> (u+v*w, u-v*w)
+// w = tw[j << (logn-1-b)] = w_n^(j*n/2^(b+1)), j = low b bits of the element index.
+// premul (optional): element i is multiplied by premul[i] as it is loaded.
+template <bool DIF>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t stride_elems, const Fr *tw, const Fr *premul,
+                                                          uint32_t logn, uint32_t lo, uint32_t t, uint32_t q) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t T = t + q, N = 1u << T;
+    Fr *x = data + (uint64_t)blockIdx.y * stride_elems;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t midw = lo - q;
+    const uint64_t mid = tile & ((1u << midw) - 1u);
+    const uint64_t hi = tile >> midw;
+    const uint64_t base = (hi << (lo + t)) | (mid << q);
+    const uint32_t cmask = (1u << q) - 1u;
+
+    for (uint32_t e = threadIdx.x; e < N; e += NTT_THREADS) {
+        uint64_t i = base | ((uint64_t)(e >> q) << lo) | (e & cmask);
+        Fr v = load_el(x + i);
+        if (premul) v = Fr::mul(v, load_el(premul + i));
+        lds_put(lds, N, e, v);
+    }
+    __syncthreads();
+
+    for (uint32_t s = 0; s < t; s++) {
+        const uint32_t rb = DIF ? (t - 1 - s) : s;
+        const uint32_t b = lo + rb;
+        const uint32_t rmask = (1u << rb) - 1u;
+        const uint32_t tshift = logn - 1 - b;
+        for (uint32_t bt = threadIdx.x; bt < (N >> 1); bt += NTT_THREADS) {
+            uint32_t c = bt & cmask, rp = bt >> q;
+            uint32_t r0 = ((rp >> rb) << (rb + 1)) | (rp & rmask);
+            uint32_t e0 = (r0 << q) | c;
+            uint32_t e1 = e0 + (1u << (rb + q));
+            uint64_t j = ((uint64_t)(r0 & rmask) << lo) | (mid << q) | c;
+            Fr u = lds_get(lds, N, e0), v = lds_get(lds, N, e1);
+            Fr s0, s1;
+            if (b == 0) {                       // w = 1
+                s0 = Fr::add(u, v);
+                s1 = Fr::sub(u, v);
+            } else {
+                Fr w = load_el(tw + (j << tshift));
+                if (DIF) {
+                    s0 = Fr::add(u, v);
+                    s1 = Fr::mul(Fr::sub(u, v), w);
+                } else {
+                    v = Fr::mul(v, w);
+                    s0 = Fr::add(u, v);
+                    s1 = Fr::sub(u, v);
+                }
+            }
+            lds_put(lds, N, e0, s0);
+            lds_put(lds, N, e1, s1);
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t e = threadIdx.x; e < N; e += NTT_THREADS) {
+        uint64_t i = base | ((uint64_t)(e >> q) << lo) | (e & cmask);
+        store_el(x + i, lds_get(lds, N, e));
+    }
+}
+
+struct PassPlan {
+    uint32_t lo[8], t[8], q[8];
+    int n;
+};
+
+// low pass covers bits [0, t0), t0 <= 11 (contiguous tile); the remaining bits are split
+// evenly into passes of <= 8 rows-bits with q = min(11 - t, lo) column bits.
+static PassPlan plan_passes(uint32_t logn) {
+    PassPlan p;
+    p.n = 0;
+    uint32_t t0 = logn < NTT_MAX_TILE_LOG ? logn : NTT_MAX_TILE_LOG;
+    p.lo[0] = 0; p.t[0] = t0; p.q[0] = 0; p.n = 1;
+    uint32_t rem = logn - t0;
+    if (rem) {
+        uint32_t k = (rem + 7) / 8;
+        uint32_t lo = t0;
+        for (uint32_t i = 0; i < k; i++) {
+            uint32_t t = rem / (k - i) + ((rem % (k - i)) ? 1 : 0);
+            uint32_t q = NTT_MAX_TILE_LOG - t;
+            if (q > lo) q = lo;
+            p.lo[p.n] = lo; p.t[p.n] = t; p.q[p.n] = q; p.n++;
+            lo += t;
+            rem -= t;
+        }
+    }
+    return p;   // ascending bit order: DIT runs 0..n-1, DIF runs n-1..0
+}
+
+template <bool DIF>
+static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const Fr *tw, const Fr *premul, uint32_t logn,
+                     uint32_t lo, uint32_t t, uint32_t q, hipStream_t s) {
+    uint32_t T = t + q;
+    uint32_t tiles = 1u << (logn - T);
+    size_t shmem = (size_t)32 << T;
+    hipLaunchKernelGGL(k_ntt_pass<DIF>, dim3(tiles, batch), dim3(NTT_THREADS), shmem, s, data, stride, tw, premul, logn, lo, t, q);
+}
+
+void launch_ntt_dif_inverse(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s) {
+    if (tb.logn == 0) return;
+    PassPlan p = plan_passes(tb.logn);
+    for (int i = p.n - 1; i >= 0; i--) run_pass<true>(data, stride, batch, tb.inv, nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
+}
+
+void launch_ntt_dit_forward(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s) {
+    if (tb.logn == 0) return;
+    PassPlan p = plan_passes(tb.logn);
+    for (int i = 0; i < p.n; i++) run_pass<false>(data, stride, batch, tb.fwd, nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
+}
+
+// ------------------------------------------------------------------ pointwise helpers
+__global__ __launch_bounds__(256) void k_scale_table(Fr *data, uint64_t stride_elems, const Fr *table, uint64_t n) {
+    Fr *x = data + (uint64_t)blockIdx.y * stride_elems;
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st)
+        store_el(x + i, Fr::mul(load_el(x + i), load_el(table + i)));
+}
+void launch_fr_scale_by_table(Fr *data, uint64_t stride, uint32_t batch, const Fr *table, uint64_t n, hipStream_t s) {
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_scale_table, dim3((uint32_t)g, batch), dim3(256), 0, s, data, stride, table, n);
+}
+
+__global__ __launch_bounds__(256) void k_scale_const(Fr *x, const Fr *k, uint64_t n) {
+    Fr kk = load_el(k);
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st)
+        store_el(x + i, Fr::mul(load_el(x + i), kk));
+}
+void launch_fr_scale_const(Fr *data, const Fr *k, uint64_t n, hipStream_t s) {
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_scale_const, dim3((uint32_t)g), dim3(256), 0, s, data, k, n);
+}
+
+__device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+__global__ __launch_bounds__(256) void k_bitrev(Fr *x, uint32_t logn) {
+    uint64_t n = 1ull << logn;
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        uint32_t j = brev((uint32_t)i, logn);
+        if (i < j) {
+            Fr a = load_el(x + i), b = load_el(x + j);
+            store_el(x + i, b);
+            store_el(x + j, a);
+        }
+    }
+}
+void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s) {
+    uint64_t n = 1ull << logn;
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_bitrev, dim3((uint32_t)g), dim3(256), 0, s, data, logn);
+}
+
+// h[i] = fromMontgomery(a[i]*b[i] - c[i])  (src/groth16.cpp:158-163): standard-form MSM scalars
+__global__ __launch_bounds__(256) void k_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n) {
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        Fr t = Fr::sub(Fr::mul(load_el(a + i), load_el(b + i)), load_el(c + i));
+        store_el(h + i, Fr::from_mont(t));
+    }
+}
+void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s) {
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_abc_to_h, dim3((uint32_t)g), dim3(256), 0, s, h, a, b, c, n);
+}
+
+// ------------------------------------------------------------------ twiddle tables
+// w_{2^28} = 5^((r-1)/2^28) (snarkjs/ffjavascript convention), standard form:
+// 19103219067921713944291392827692070036145651957329286315305642004821462161904
+__device__ __constant__ const uint32_t ROOT_2_28_STD[8] = {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu,
+                                                           0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u};
+
+__device__ Fr fr_pow(Fr base, uint64_t e) {
+    Fr r = Fr::one();
+    while (e) {
+        if (e & 1) r = Fr::mul(r, base);
+        base = Fr::sqr(base);
+        e >>= 1;
+    }
+    return r;
+}
+
+// w_{2^k} in Montgomery form
+__device__ Fr fr_root_of_unity(uint32_t k) {
+    Fr w;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.v[i] = ROOT_2_28_STD[i];
+    w = Fr::to_mont(w);
+    for (uint32_t i = k; i < 28; i++) w = Fr::sqr(w);
+    return w;
+}
+
+__global__ __launch_bounds__(256) void k_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv_out, uint32_t logn) {
+    const uint64_t n = 1ull << logn;
+    __shared__ Fr s_wn, s_wninv, s_w2n, s_ninv;
+    if (threadIdx.x == 0) {
+        Fr wn = fr_root_of_unity(logn);
+        s_wn = wn;
+        s_wninv = Fr::inv(wn);
+        s_w2n = fr_root_of_unity(logn + 1);
+        // n^-1: Montgomery form of n is to_mont(n)
+        Fr nn = Fr::zero();
+        nn.v[0] = (uint32_t)n;
+        nn.v[1] = (uint32_t)(n >> 32);
+        s_ninv = Fr::inv(Fr::to_mont(nn));
+    }
+    __syncthreads();
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        if (i < (n >> 1) || n == 1) {
+            if (n > 1) {
+                store_el(fwd + i, fr_pow(s_wn, i));
+                store_el(inv + i, fr_pow(s_wninv, i));
+            }
+        }
+        uint32_t k = brev((uint32_t)i, logn);
+        store_el(coset + i, Fr::mul(fr_pow(s_w2n, k), s_ninv));
+        if (i == 0) store_el(ninv_out, s_ninv);
+    }
+}
+
+void launch_ntt_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s) {
+    uint64_t n = 1ull << logn;
+    uint64_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_build_tables, dim3((uint32_t)g), dim3(256), 0, s, fwd, inv, coset, ninv, logn);
+}
+
+}   // namespace zk

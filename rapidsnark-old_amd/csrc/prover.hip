@@ -1,0 +1,619 @@
+// C-ABI of libzkhip (include/zkhip.h): the MI355X replacement of
+// Groth16::makeProver / Prover::prove (reference src/groth16.cpp:9-254).
+//
+// zk_prover_create does the one-off work (CSR of the coefficient records, point tables and
+// twiddles resident in HBM); zk_prove* run the per-proof pipeline:
+//   SpMV -> c=a.b -> 3x(DIF iNTT, coset*1/n, DIT NTT) -> h -> digits/sort(w), digits/sort(h)
+//   -> bucket accumulation A,B1,C,H (G1) and B2 (G2) -> bucket reduce -> host Horner + assembly.
+// No CPU fallback exists: every entry point fails if HIP does.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/random.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <memory>
+#include <stdexcept>
+
+#include "../../include/zkhip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+using namespace zk;
+
+namespace {
+
+struct HipError {
+    std::string msg;
+};
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) throw HipError{std::string(#expr) + ": " + hipGetErrorString(_e)};   \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_TRY(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void upload(const void *src, size_t count, hipStream_t s) {
+        if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+};
+
+struct Slice {
+    uint64_t lo, hi;
+    uint64_t size() const { return hi - lo; }
+};
+static Slice shard_slice(uint64_t n, uint32_t idx, uint32_t cnt) {
+    uint64_t per = (n + cnt - 1) / cnt;
+    uint64_t lo = per * idx, hi = lo + per;
+    if (lo > n) lo = n;
+    if (hi > n) hi = n;
+    return Slice{lo, hi};
+}
+
+// Scalar-vector sort workspace (one per scalar set: witness, h)
+struct SortBufs {
+    MsmPlan plan;
+    uint64_t n = 0;
+    DevBuf<uint32_t> counts, offsets, cursor, entries;
+    uint32_t total_buckets() const { return plan.W * plan.nbuckets; }
+    void alloc(uint64_t n_, uint32_t window_bits) {
+        n = n_;
+        plan = make_msm_plan(n ? n : 1, window_bits);
+        counts.alloc(total_buckets());
+        offsets.alloc(total_buckets() + 1);
+        cursor.alloc(total_buckets());
+        entries.alloc((size_t)(n ? n : 1) * plan.W);
+    }
+    void run(const Fr *scalars, hipStream_t s) {
+        HIP_TRY(hipMemsetAsync(counts.p, 0, counts.n * 4, s));
+        launch_msm_count(counts.p, scalars, n, plan, s);
+        launch_msm_scan(offsets.p, cursor.p, counts.p, total_buckets(), s);
+        launch_msm_scatter(entries.p, cursor.p, scalars, n, plan, s);
+    }
+};
+
+}   // namespace
+
+struct zk_prover {
+    int device = 0;
+    uint32_t flags = 0;
+    uint32_t nVars = 0, nPublic = 0, domainSize = 0, logn = 0;
+    uint64_t nCoefs = 0;
+    uint32_t shard_index = 0, shard_count = 1;
+    uint8_t vk_alpha1[64], vk_beta1[64], vk_beta2[128], vk_delta1[64], vk_delta2[128];
+    hipStream_t stream = nullptr;
+    std::mutex mtx;
+
+    // resident data
+    DevBuf<uint32_t> csr_rowptr, csr_col;
+    DevBuf<Fr> csr_val;
+    DevBuf<Fr> tw_fwd, tw_inv, tw_coset, tw_ninv;
+    Slice sv, sh;              // this shard's slice of witness indices / domain indices
+    uint32_t c_idx_min = 0;    // C-MSM: local witness index >= c_idx_min maps to pointsC[idx - c_idx_min]
+    DevBuf<G1Affine> ptsA, ptsB1, ptsC, ptsH;
+    DevBuf<G2Affine> ptsB2;
+
+    // per-proof workspace
+    DevBuf<Fr> wtns, abc, h;   // abc = a|b|c back to back
+    SortBufs sort_w, sort_h;
+    DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
+    DevBuf<G2XYZZ> buckets_g2;
+    DevBuf<G1XYZZ> scratch_g1, wsum_g1;
+    DevBuf<G2XYZZ> scratch_g2, wsum_g2;
+
+    hipEvent_t ev[10];
+    bool have_events = false;
+    double timings[ZK_T_COUNT] = {0};
+    uint32_t accum_launches = 0;
+
+    ~zk_prover() {
+        if (have_events)
+            for (auto &e : ev) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        HIP_TRY(hipSetDevice(dev));
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <class Fn>
+int guarded(Fn fn) {
+    try {
+        fn();
+        return 0;
+    } catch (const HipError &e) {
+        set_error("HIP failure: " + e.msg);
+        return 2;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return 1;
+    }
+}
+
+uint32_t ilog2_exact(uint64_t n) {
+    uint32_t l = 0;
+    while ((1ull << l) < n) l++;
+    if ((1ull << l) != n) throw std::invalid_argument("domainSize is not a power of two");
+    return l;
+}
+
+// Row-sorted CSR of the packed 44-byte Coef records (src/groth16.hpp:27-35), counting sort.
+void build_csr(const uint8_t *coefs /* after the u32 count */, uint64_t nCoefs, uint32_t n, uint32_t nVars,
+               std::vector<uint32_t> &rowptr, std::vector<uint32_t> &col, std::vector<uint8_t> &val) {
+    rowptr.assign((size_t)2 * n + 1, 0);
+    for (uint64_t i = 0; i < nCoefs; i++) {
+        const uint8_t *rec = coefs + i * 44;
+        uint32_t m, c, s;
+        memcpy(&m, rec, 4);
+        memcpy(&c, rec + 4, 4);
+        memcpy(&s, rec + 8, 4);
+        if (m > 1 || c >= n || s >= nVars) throw std::invalid_argument("zkey coefficient record out of range");
+        rowptr[(size_t)m * n + c + 1]++;
+    }
+    for (size_t r = 0; r < (size_t)2 * n; r++) rowptr[r + 1] += rowptr[r];
+    col.resize(nCoefs);
+    val.resize((size_t)nCoefs * 32);
+    std::vector<uint32_t> cur(rowptr.begin(), rowptr.end() - 1);
+    for (uint64_t i = 0; i < nCoefs; i++) {
+        const uint8_t *rec = coefs + i * 44;
+        uint32_t m, c, s;
+        memcpy(&m, rec, 4);
+        memcpy(&c, rec + 4, 4);
+        memcpy(&s, rec + 8, 4);
+        uint32_t pos = cur[(size_t)m * n + c]++;
+        col[pos] = s;
+        memcpy(&val[(size_t)pos * 32], rec + 12, 32);
+    }
+}
+
+void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
+    if (!out || !z) throw std::invalid_argument("null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw std::runtime_error("no HIP device available (libzkhip has no CPU fallback)");
+    std::unique_ptr<zk_prover> p(new zk_prover());
+    int dev = (o && o->device >= 0) ? o->device : -1;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    p->device = dev;
+    DeviceGuard g(dev);
+    p->flags = o ? o->flags : 0;
+    p->shard_count = (o && o->shard_count > 1) ? o->shard_count : 1;
+    p->shard_index = o ? o->shard_index : 0;
+    if (p->shard_index >= p->shard_count) throw std::invalid_argument("shard_index >= shard_count");
+    const uint32_t wbits = o ? o->window_bits : 0;
+
+    p->nVars = z->nVars;
+    p->nPublic = z->nPublic;
+    p->domainSize = z->domainSize;
+    p->nCoefs = z->nCoefs;
+    if (z->nVars == 0 || z->nPublic + 1 > z->nVars) throw std::invalid_argument("invalid nVars/nPublic");
+    p->logn = ilog2_exact(z->domainSize);
+    if (p->logn > 28) throw std::invalid_argument("domainSize exceeds the 2-adicity of BN254 Fr (2^28)");
+    const uint64_t n = z->domainSize, nV = z->nVars, nC = nV - z->nPublic - 1;
+    // section size checks (the reference does none; an undersized section would be an OOB read)
+    if (z->coefs_bytes && z->coefs_bytes < 4 + z->nCoefs * 44) throw std::invalid_argument("zkey section 4 too small");
+    if (z->pointsA_bytes && z->pointsA_bytes < nV * 64) throw std::invalid_argument("zkey section 5 too small");
+    if (z->pointsB1_bytes && z->pointsB1_bytes < nV * 64) throw std::invalid_argument("zkey section 6 too small");
+    if (z->pointsB2_bytes && z->pointsB2_bytes < nV * 128) throw std::invalid_argument("zkey section 7 too small");
+    if (z->pointsC_bytes && z->pointsC_bytes < nC * 64) throw std::invalid_argument("zkey section 8 too small");
+    if (z->pointsH_bytes && z->pointsH_bytes < n * 64) throw std::invalid_argument("zkey section 9 too small");
+    memcpy(p->vk_alpha1, z->vk_alpha1, 64);
+    memcpy(p->vk_beta1, z->vk_beta1, 64);
+    memcpy(p->vk_beta2, z->vk_beta2, 128);
+    memcpy(p->vk_delta1, z->vk_delta1, 64);
+    memcpy(p->vk_delta2, z->vk_delta2, 128);
+
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    hipStream_t s = p->stream;
+
+    // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4)
+    std::vector<uint32_t> rowptr, col;
+    std::vector<uint8_t> val;
+    build_csr((const uint8_t *)z->coefs + 4, z->nCoefs, z->domainSize, z->nVars, rowptr, col, val);
+    p->csr_rowptr.alloc(rowptr.size());
+    p->csr_col.alloc(col.size() ? col.size() : 1);
+    p->csr_val.alloc(col.size() ? col.size() : 1);
+    p->csr_rowptr.upload(rowptr.data(), rowptr.size(), s);
+    p->csr_col.upload(col.data(), col.size(), s);
+    p->csr_val.upload(val.data(), col.size(), s);
+
+    // --- twiddles
+    p->tw_fwd.alloc(n > 1 ? n / 2 : 1);
+    p->tw_inv.alloc(n > 1 ? n / 2 : 1);
+    p->tw_coset.alloc(n);
+    p->tw_ninv.alloc(1);
+    launch_ntt_build_tables(p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p, p->logn, s);
+
+    // --- point tables: this shard's contiguous slices
+    p->sv = shard_slice(nV, p->shard_index, p->shard_count);
+    p->sh = shard_slice(n, p->shard_index, p->shard_count);
+    const uint64_t nv = p->sv.size(), nh = p->sh.size();
+    p->ptsA.alloc(nv ? nv : 1);
+    p->ptsB1.alloc(nv ? nv : 1);
+    p->ptsB2.alloc(nv ? nv : 1);
+    p->ptsH.alloc(nh ? nh : 1);
+    p->ptsA.upload((const uint8_t *)z->pointsA + p->sv.lo * 64, nv, s);
+    p->ptsB1.upload((const uint8_t *)z->pointsB1 + p->sv.lo * 64, nv, s);
+    p->ptsB2.upload((const uint8_t *)z->pointsB2 + p->sv.lo * 128, nv, s);
+    p->ptsH.upload((const uint8_t *)z->pointsH + p->sh.lo * 64, nh, s);
+    // C: witness index i (global) uses pointsC[i - nPublic - 1] for i > nPublic (src/groth16.cpp:204)
+    {
+        uint64_t first = z->nPublic + 1;                 // first global witness index with a C point
+        uint64_t lo = p->sv.lo > first ? p->sv.lo : first;
+        uint64_t hi = p->sv.hi > lo ? p->sv.hi : lo;
+        p->c_idx_min = (uint32_t)(lo - p->sv.lo);
+        uint64_t cnt = hi - lo;
+        p->ptsC.alloc(cnt ? cnt : 1);
+        p->ptsC.upload((const uint8_t *)z->pointsC + (lo - first) * 64, cnt, s);
+    }
+
+    // --- workspace
+    p->wtns.alloc(nV);
+    p->abc.alloc(3 * n);
+    p->h.alloc(n);
+    p->sort_w.alloc(nv, wbits);
+    p->sort_h.alloc(nh, wbits);
+    const uint64_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
+    p->buckets_g1.alloc(3 * tbw + tbh);
+    p->buckets_g2.alloc(tbw);
+    {
+        uint64_t s1 = msm_reduce_scratch_points(3, p->sort_w.plan) + msm_reduce_scratch_points(1, p->sort_h.plan);
+        p->scratch_g1.alloc(s1);
+        p->wsum_g1.alloc(3 * p->sort_w.plan.W + p->sort_h.plan.W);
+        p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
+        p->wsum_g2.alloc(p->sort_w.plan.W);
+    }
+    for (auto &e : p->ev) HIP_TRY(hipEventCreate(&e));
+    p->have_events = true;
+    HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
+    *out = p.release();
+}
+
+// Steps 1-10 of prove() on the device + Horner on the host.  d_wtns: device pointer, nVars x 32 B.
+void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
+    std::lock_guard<std::mutex> lk(p->mtx);
+    DeviceGuard g(p->device);
+    hipStream_t s = p->stream;
+    const uint64_t n = p->domainSize;
+    const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
+    auto mark = [&](int i) {
+        if (tm) HIP_TRY(hipEventRecord(p->ev[i], s));
+    };
+    Fr *a = p->abc.p, *b = p->abc.p + n, *c = p->abc.p + 2 * n;
+
+    mark(0);
+    // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96)
+    CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
+    launch_spmv_abc(a, b, c, csr, d_wtns, p->domainSize, s);
+    mark(1);
+    // 4: three coset evaluations (src/groth16.cpp:98-155), batched, no bit-reversal pass
+    NttTables tb{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p};
+    launch_ntt_dif_inverse(p->abc.p, n, 3, tb, s);
+    launch_fr_scale_by_table(p->abc.p, n, 3, p->tw_coset.p, n, s);
+    launch_ntt_dit_forward(p->abc.p, n, 3, tb, s);
+    // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
+    launch_abc_to_h(p->h.p, a, b, c, n, s);
+    mark(2);
+    // digits + counting sort: once for the witness slice (shared by A,B1,B2,C), once for h
+    p->sort_w.run(d_wtns + p->sv.lo, s);
+    p->sort_h.run(p->h.p + p->sh.lo, s);
+    mark(3);
+    // 6-10: bucket accumulation
+    const uint32_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
+    G1XYZZ *bA = p->buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
+    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, s);
+    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, s);
+    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, s);
+    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, s);
+    mark(4);
+    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, s);
+    mark(5);
+    // bucket reduction -> window sums
+    const uint32_t Ww = p->sort_w.plan.W, Wh = p->sort_h.plan.W;
+    launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 3, p->sort_w.plan, s);
+    launch_msm_reduce_g1(p->wsum_g1.p + 3 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(3, p->sort_w.plan), bH, 1, p->sort_h.plan, s);
+    launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, p->sort_w.plan, s);
+    mark(6);
+    std::vector<uint8_t> w1((size_t)(3 * Ww + Wh) * sizeof(G1XYZZ)), w2((size_t)Ww * sizeof(G2XYZZ));
+    HIP_TRY(hipMemcpyAsync(w1.data(), p->wsum_g1.p, w1.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(w2.data(), p->wsum_g2.p, w2.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (tm) {
+        float ms[7];
+        for (int i = 0; i < 6; i++) HIP_TRY(hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms[6], p->ev[0], p->ev[6]));
+        p->timings[ZK_T_SPMV] = ms[0];
+        p->timings[ZK_T_NTT] = ms[1];
+        p->timings[ZK_T_DIGITS_SORT] = ms[2];
+        p->timings[ZK_T_MSM_G1_ACCUM] = ms[3];
+        p->timings[ZK_T_MSM_G2_ACCUM] = ms[4];
+        p->timings[ZK_T_MSM_REDUCE] = ms[5];
+        p->timings[ZK_T_TOTAL_DEVICE] = ms[6];
+        p->timings[ZK_T_ACCUM_LAUNCHES] = 4;
+    }
+    // host Horner over windows (c doublings per window)
+    const uint32_t cw = p->sort_w.plan.c, ch = p->sort_h.plan.c;
+    const size_t P1 = sizeof(G1XYZZ);
+    HostTail::combine_windows_g1(w1.data(), Ww, cw, out->pi_a);
+    HostTail::combine_windows_g1(w1.data() + (size_t)Ww * P1, Ww, cw, out->pib1);
+    HostTail::combine_windows_g1(w1.data() + (size_t)2 * Ww * P1, Ww, cw, out->pi_c);
+    HostTail::combine_windows_g1(w1.data() + (size_t)3 * Ww * P1, Wh, ch, out->pih);
+    HostTail::combine_windows_g2(w2.data(), Ww, cw, out->pi_b);
+}
+
+void draw_rs(uint8_t out[32]) {
+    // src/groth16.cpp:213-217: zero, then 31 random bytes into the low bytes
+    memset(out, 0, 32);
+    size_t got = 0;
+    while (got < 31) {
+        ssize_t k = getrandom(out + got, 31 - got, 0);
+        if (k < 0) throw std::runtime_error("getrandom failed");
+        got += (size_t)k;
+    }
+}
+
+void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
+    if (!nparts) throw std::invalid_argument("no partial sums");
+    zk_msm_sums t = parts[0];
+    for (uint32_t i = 1; i < nparts; i++) {
+        HostTail::add_affine_g1(t.pih, parts[i].pih);
+        HostTail::add_affine_g1(t.pi_a, parts[i].pi_a);
+        HostTail::add_affine_g1(t.pib1, parts[i].pib1);
+        HostTail::add_affine_g2(t.pi_b, parts[i].pi_b);
+        HostTail::add_affine_g1(t.pi_c, parts[i].pi_c);
+    }
+    uint8_t r[32], s[32];
+    if (r32) memcpy(r, r32, 32); else draw_rs(r);
+    if (s32) memcpy(s, s32, 32); else draw_rs(s);
+    HostTail::final_assembly(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, t.pih, t.pi_a, t.pib1,
+                             t.pi_b, t.pi_c, r, s, out->A, out->B, out->C);
+}
+
+const Fr *stage_witness(zk_prover *p, const uint8_t *wtns) {
+    DeviceGuard g(p->device);
+    HIP_TRY(hipMemcpyAsync(p->wtns.p, wtns, (size_t)p->nVars * 32, hipMemcpyHostToDevice, p->stream));
+    return p->wtns.p;
+}
+
+}   // namespace
+
+extern "C" {
+
+int zk_device_count(int *count) {
+    return guarded([&] {
+        int n = 0;
+        HIP_TRY(hipGetDeviceCount(&n));
+        *count = n;
+    });
+}
+
+int zk_prover_create(zk_prover **out, const zk_zkey_view *zkey, const zk_opts *opts) {
+    return guarded([&] { prover_create(out, zkey, opts); });
+}
+
+void zk_prover_destroy(zk_prover *p) {
+    if (!p) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->device);
+    delete p;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int zk_prove_msm_dev(zk_prover *p, const void *d_wtns, zk_msm_sums *partial) {
+    return guarded([&] {
+        if (!p || !d_wtns || !partial) throw std::invalid_argument("null argument");
+        prove_msm(p, (const Fr *)d_wtns, partial);
+    });
+}
+
+int zk_prove_msm(zk_prover *p, const uint8_t *wtns, zk_msm_sums *partial) {
+    return guarded([&] {
+        if (!p || !wtns || !partial) throw std::invalid_argument("null argument");
+        prove_msm(p, stage_witness(p, wtns), partial);
+    });
+}
+
+int zk_prove_finish(zk_prover *p, const zk_msm_sums *partials, uint32_t n_partials, const uint8_t *r32, const uint8_t *s32,
+                    zk_proof *out) {
+    return guarded([&] {
+        if (!p || !partials || !out) throw std::invalid_argument("null argument");
+        prove_finish(p, partials, n_partials, r32, s32, out);
+    });
+}
+
+int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
+    return guarded([&] {
+        if (!p || !d_wtns || !out) throw std::invalid_argument("null argument");
+        if (p->shard_count != 1) throw std::invalid_argument("zk_prove on a sharded prover: use zk_prove_msm + zk_prove_finish");
+        zk_msm_sums sums;
+        prove_msm(p, (const Fr *)d_wtns, &sums);
+        prove_finish(p, &sums, 1, r32, s32, out);
+    });
+}
+
+int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
+    return guarded([&] {
+        if (!p || !wtns || !out) throw std::invalid_argument("null argument");
+        if (p->shard_count != 1) throw std::invalid_argument("zk_prove on a sharded prover: use zk_prove_msm + zk_prove_finish");
+        zk_msm_sums sums;
+        prove_msm(p, stage_witness(p, wtns), &sums);
+        prove_finish(p, &sums, 1, r32, s32, out);
+    });
+}
+
+int zk_prover_timings(zk_prover *p, double *ms, uint32_t n) {
+    return guarded([&] {
+        if (!p || !ms) throw std::invalid_argument("null argument");
+        if (!(p->flags & ZK_FLAG_TIMINGS)) throw std::invalid_argument("prover created without ZK_FLAG_TIMINGS");
+        for (uint32_t i = 0; i < n && i < ZK_T_COUNT; i++) ms[i] = p->timings[i];
+    });
+}
+
+}   // extern "C"
+
+// ------------------------------------------------------------------ operator level
+static void need_device() {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw std::runtime_error("no HIP device available (libzkhip has no CPU fallback)");
+}
+
+template <class F>
+static void mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n, void (*launch)(F *, const F *, const F *, uint64_t, hipStream_t)) {
+    need_device();
+    if (!n) return;
+    DevBuf<F> da, db;
+    da.alloc(n);
+    db.alloc(n);
+    da.upload(a, n, 0);
+    db.upload(b, n, 0);
+    launch(da.p, da.p, db.p, n, 0);
+    HIP_TRY(hipMemcpy(out, da.p, n * 32, hipMemcpyDeviceToHost));
+}
+
+struct Tables {
+    DevBuf<Fr> fwd, inv, coset, ninv;
+    NttTables t;
+    void build(uint32_t logn) {
+        uint64_t n = 1ull << logn;
+        fwd.alloc(n > 1 ? n / 2 : 1);
+        inv.alloc(n > 1 ? n / 2 : 1);
+        coset.alloc(n);
+        ninv.alloc(1);
+        launch_ntt_build_tables(fwd.p, inv.p, coset.p, ninv.p, logn, 0);
+        t = NttTables{logn, fwd.p, inv.p, coset.p, ninv.p};
+    }
+};
+
+template <class AffT, class XT>
+static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scalars, uint64_t n, bool g2);
+
+extern "C" {
+
+int zk_fr_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n) {
+    return guarded([&] { mul_vec<Fr>(out, a, b, n, launch_fr_mul_vec); });
+}
+int zk_fq_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n) {
+    return guarded([&] { mul_vec<Fq>(out, a, b, n, launch_fq_mul_vec); });
+}
+
+int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse) {
+    return guarded([&] {
+        need_device();
+        uint32_t logn = ilog2_exact(n);
+        if (logn > 28) throw std::invalid_argument("n exceeds 2^28");
+        Tables tb;
+        tb.build(logn);
+        DevBuf<Fr> d;
+        d.alloc(n);
+        d.upload(data, n, 0);
+        if (inverse) {
+            launch_ntt_dif_inverse(d.p, n, 1, tb.t, 0);
+            launch_bitrev_permute(d.p, logn, 0);
+            launch_fr_scale_const(d.p, tb.ninv.p, n, 0);
+        } else {
+            launch_bitrev_permute(d.p, logn, 0);
+            launch_ntt_dit_forward(d.p, n, 1, tb.t, 0);
+        }
+        HIP_TRY(hipMemcpy(data, d.p, n * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+int zk_fr_abc_to_h(uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n) {
+    return guarded([&] {
+        need_device();
+        uint32_t logn = ilog2_exact(n);
+        if (logn > 27) throw std::invalid_argument("n exceeds 2^27");
+        Tables tb;
+        tb.build(logn);
+        DevBuf<Fr> abc, hh;
+        abc.alloc(3 * n);
+        hh.alloc(n);
+        HIP_TRY(hipMemcpy(abc.p, a, n * 32, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(abc.p + n, b, n * 32, hipMemcpyHostToDevice));
+        launch_fr_mul_vec(abc.p + 2 * n, abc.p, abc.p + n, n, 0);
+        launch_ntt_dif_inverse(abc.p, n, 3, tb.t, 0);
+        launch_fr_scale_by_table(abc.p, n, 3, tb.coset.p, n, 0);
+        launch_ntt_dit_forward(abc.p, n, 3, tb.t, 0);
+        launch_abc_to_h(hh.p, abc.p, abc.p + n, abc.p + 2 * n, n, 0);
+        HIP_TRY(hipMemcpy(h, hh.p, n * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+}   // extern "C"
+
+template <class AffT, class XT>
+static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scalars, uint64_t n, bool g2) {
+    need_device();
+    if (n >= (1ull << 31)) throw std::invalid_argument("n too large");
+    if (n == 0) {
+        memset(out, 0, sizeof(AffT));
+        return;
+    }
+    DevBuf<AffT> pts;
+    DevBuf<Fr> sc;
+    pts.alloc(n);
+    sc.alloc(n);
+    pts.upload(bases, n, 0);
+    sc.upload(scalars, n, 0);
+    SortBufs sb;
+    sb.alloc(n, 0);
+    sb.run(sc.p, 0);
+    DevBuf<XT> buckets, scratch, wsum;
+    buckets.alloc(sb.total_buckets());
+    scratch.alloc(msm_reduce_scratch_points(1, sb.plan));
+    wsum.alloc(sb.plan.W);
+    std::vector<uint8_t> w((size_t)sb.plan.W * sizeof(XT));
+    if constexpr (sizeof(AffT) == 64) {
+        launch_msm_accum_g1((G1XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), 0);
+        launch_msm_reduce_g1((G1XYZZ *)wsum.p, (G1XYZZ *)scratch.p, (const G1XYZZ *)buckets.p, 1, sb.plan, 0);
+    } else {
+        launch_msm_accum_g2((G2XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G2Affine *)pts.p, 0, 0, sb.total_buckets(), 0);
+        launch_msm_reduce_g2((G2XYZZ *)wsum.p, (G2XYZZ *)scratch.p, (const G2XYZZ *)buckets.p, 1, sb.plan, 0);
+    }
+    HIP_TRY(hipMemcpy(w.data(), wsum.p, w.size(), hipMemcpyDeviceToHost));
+    if (g2) HostTail::combine_windows_g2(w.data(), sb.plan.W, sb.plan.c, out);
+    else HostTail::combine_windows_g1(w.data(), sb.plan.W, sb.plan.c, out);
+}
+
+extern "C" {
+
+int zk_msm_g1(uint8_t out[64], const uint8_t *bases, const uint8_t *scalars, uint64_t n) {
+    return guarded([&] { msm_generic<G1Affine, G1XYZZ>(out, bases, scalars, n, false); });
+}
+int zk_msm_g2(uint8_t out[128], const uint8_t *bases, const uint8_t *scalars, uint64_t n) {
+    return guarded([&] { msm_generic<G2Affine, G2XYZZ>(out, bases, scalars, n, true); });
+}
+
+}   // extern "C"

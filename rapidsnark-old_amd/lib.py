@@ -1,0 +1,174 @@
+"""ctypes binding of include/zkhip.h.  Fails loudly when libzkhip.so is absent — there is
+no Python or CPU fallback for any compute entry point."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class ZkHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libzkhip.so")
+
+
+class zk_zkey_view(C.Structure):
+    _fields_ = [("nVars", C.c_uint32), ("nPublic", C.c_uint32), ("domainSize", C.c_uint32), ("nCoefs", C.c_uint64),
+                ("vk_alpha1", C.c_void_p), ("vk_beta1", C.c_void_p), ("vk_beta2", C.c_void_p),
+                ("vk_delta1", C.c_void_p), ("vk_delta2", C.c_void_p), ("coefs", C.c_void_p),
+                ("pointsA", C.c_void_p), ("pointsB1", C.c_void_p), ("pointsB2", C.c_void_p),
+                ("pointsC", C.c_void_p), ("pointsH", C.c_void_p),
+                ("coefs_bytes", C.c_uint64), ("pointsA_bytes", C.c_uint64), ("pointsB1_bytes", C.c_uint64),
+                ("pointsB2_bytes", C.c_uint64), ("pointsC_bytes", C.c_uint64), ("pointsH_bytes", C.c_uint64)]
+
+
+class zk_opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("window_bits", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class zk_proof(C.Structure):
+    _fields_ = [("A", C.c_uint8 * 64), ("B", C.c_uint8 * 128), ("C", C.c_uint8 * 64)]
+
+
+class zk_msm_sums(C.Structure):
+    _fields_ = [("pih", C.c_uint8 * 64), ("pi_a", C.c_uint8 * 64), ("pib1", C.c_uint8 * 64),
+                ("pi_b", C.c_uint8 * 128), ("pi_c", C.c_uint8 * 64)]
+
+
+ZK_FLAG_TIMINGS = 1
+ZK_T_NAMES = ["spmv", "ntt", "digits_sort", "msm_g1_accum", "msm_g2_accum", "msm_reduce", "total_device", "accum_launches"]
+
+# every symbol include/zkhip.h declares (tests check the library exports all of them)
+EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
+           "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
+           "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
+           "zk_public_to_json"]
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ZkHipError("libzkhip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "or `make -C rapidsnark-old_amd/csrc`; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.zk_last_error.restype = C.c_char_p
+    u8p = C.c_void_p
+    lib.zk_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.zk_prover_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(zk_zkey_view), C.POINTER(zk_opts)]
+    lib.zk_prover_destroy.argtypes = [C.c_void_p]
+    lib.zk_prover_destroy.restype = None
+    lib.zk_prove.argtypes = [C.c_void_p, u8p, u8p, u8p, C.POINTER(zk_proof)]
+    lib.zk_prove_dev.argtypes = [C.c_void_p, C.c_void_p, u8p, u8p, C.POINTER(zk_proof)]
+    lib.zk_prove_msm.argtypes = [C.c_void_p, u8p, C.POINTER(zk_msm_sums)]
+    lib.zk_prove_msm_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(zk_msm_sums)]
+    lib.zk_prove_finish.argtypes = [C.c_void_p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
+    lib.zk_prover_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
+    for name in ("zk_fr_mul_vec", "zk_fq_mul_vec"):
+        getattr(lib, name).argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_fr_ntt.argtypes = [u8p, C.c_uint64, C.c_int]
+    lib.zk_fr_abc_to_h.argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_msm_g1.argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_msm_g2.argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_proof_to_json.argtypes = [C.POINTER(zk_proof), C.c_char_p, C.c_size_t]
+    lib.zk_proof_to_json.restype = C.c_size_t
+    lib.zk_public_to_json.argtypes = [u8p, C.c_uint32, C.c_char_p, C.c_size_t]
+    lib.zk_public_to_json.restype = C.c_size_t
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ZkHipError(load_library().zk_last_error().decode("utf-8", "replace"))
+
+
+def _buf(b, nbytes=None):
+    """bytes / bytearray / numpy uint8 -> contiguous numpy uint8 array (kept alive by caller)."""
+    a = np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b).view(np.uint8).reshape(-1)
+    if nbytes is not None and a.size != nbytes:
+        raise ValueError("expected %d bytes, got %d" % (nbytes, a.size))
+    return a
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load_library().zk_device_count(C.byref(n)))
+    return n.value
+
+
+def _mul_vec(fn, a, b):
+    a, b = _buf(a), _buf(b)
+    assert a.size == b.size and a.size % 32 == 0
+    out = np.empty_like(a)
+    check(fn(_ptr(out), _ptr(a), _ptr(b), a.size // 32))
+    return out.tobytes()
+
+
+def fr_mul_vec(a, b):
+    return _mul_vec(load_library().zk_fr_mul_vec, a, b)
+
+
+def fq_mul_vec(a, b):
+    return _mul_vec(load_library().zk_fq_mul_vec, a, b)
+
+
+def fr_ntt(data, inverse=False):
+    a = _buf(data).copy()
+    check(load_library().zk_fr_ntt(_ptr(a), a.size // 32, 1 if inverse else 0))
+    return a.tobytes()
+
+
+def fr_abc_to_h(a, b):
+    a, b = _buf(a), _buf(b)
+    out = np.empty_like(a)
+    check(load_library().zk_fr_abc_to_h(_ptr(out), _ptr(a), _ptr(b), a.size // 32))
+    return out.tobytes()
+
+
+def msm_g1(bases, scalars):
+    bases, scalars = _buf(bases), _buf(scalars)
+    n = scalars.size // 32
+    assert bases.size == n * 64
+    out = np.zeros(64, dtype=np.uint8)
+    check(load_library().zk_msm_g1(_ptr(out), _ptr(bases), _ptr(scalars), n))
+    return out.tobytes()
+
+
+def msm_g2(bases, scalars):
+    bases, scalars = _buf(bases), _buf(scalars)
+    n = scalars.size // 32
+    assert bases.size == n * 128
+    out = np.zeros(128, dtype=np.uint8)
+    check(load_library().zk_msm_g2(_ptr(out), _ptr(bases), _ptr(scalars), n))
+    return out.tobytes()
+
+
+def proof_to_json(proof_bytes):
+    p = zk_proof.from_buffer_copy(bytes(proof_bytes))
+    lib = load_library()
+    n = lib.zk_proof_to_json(C.byref(p), None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.zk_proof_to_json(C.byref(p), buf, n + 1)
+    return buf.value.decode()
+
+
+def public_to_json(wtns_values_bytes, n_public):
+    a = _buf(wtns_values_bytes)
+    lib = load_library()
+    n = lib.zk_public_to_json(_ptr(a), n_public, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.zk_public_to_json(_ptr(a), n_public, buf, n + 1)
+    return buf.value.decode()

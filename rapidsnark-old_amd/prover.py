@@ -1,0 +1,124 @@
+"""Groth16::Prover mirror over the C-ABI (reference src/groth16.hpp:37-121,
+src/main_prover.cpp:23-103).  Prover(zkey) == makeProver; prove(wtns) == Prover::prove."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+from .binfile import open_existing
+from .zkey import load_zkey_header
+from .wtns import load_wtns_header
+
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617   # main_prover.cpp:34
+
+
+class Prover:
+    def __init__(self, zkey, device=-1, shard_index=0, shard_count=1, window_bits=0, timings=False):
+        """zkey: path or bytes of a snarkjs .zkey (version <= 1, main_prover.cpp:42)."""
+        self._lib = L.load_library()
+        f = open_existing(zkey, "zkey", 1)
+        h = load_zkey_header(f)
+        if h.rPrime != BN254_R:
+            raise ValueError("zkey curve not supported")            # main_prover.cpp:46-48
+        self.header = h
+        self._keep = []
+        v = L.zk_zkey_view()
+        v.nVars, v.nPublic, v.domainSize, v.nCoefs = h.nVars, h.nPublic, h.domainSize, h.nCoefs
+
+        def ptr(b):
+            a = np.frombuffer(b, dtype=np.uint8)
+            self._keep.append(a)
+            return a.ctypes.data if a.size else None
+
+        v.vk_alpha1, v.vk_beta1, v.vk_beta2 = ptr(h.vk_alpha1), ptr(h.vk_beta1), ptr(h.vk_beta2)
+        v.vk_delta1, v.vk_delta2 = ptr(h.vk_delta1), ptr(h.vk_delta2)
+        for name, sec in (("coefs", 4), ("pointsA", 5), ("pointsB1", 6), ("pointsB2", 7), ("pointsC", 8), ("pointsH", 9)):
+            data = f.getSectionData(sec)                              # main_prover.cpp:67-72
+            setattr(v, name, ptr(data))
+            setattr(v, name + "_bytes", len(data))
+        o = L.zk_opts(device, shard_index, shard_count, window_bits, L.ZK_FLAG_TIMINGS if timings else 0)
+        self._h = C.c_void_p()
+        L.check(self._lib.zk_prover_create(C.byref(self._h), C.byref(v), C.byref(o)))
+        self._keep = []     # host image may be released after create (include/zkhip.h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.zk_prover_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    @staticmethod
+    def _rs(x):
+        if x is None:
+            return None, None
+        a = np.frombuffer(int(x).to_bytes(32, "little") if not isinstance(x, (bytes, bytearray)) else bytes(x), dtype=np.uint8)
+        return a, C.c_void_p(a.ctypes.data)
+
+    def _wtns_values(self, wtns):
+        """Accepts a .wtns path/bytes (binfile) or raw nVars*32 value bytes."""
+        if isinstance(wtns, str) or bytes(wtns[:4]) == b"wtns":
+            f = open_existing(wtns, "wtns", 2)                        # main_prover.cpp:50
+            wh = load_wtns_header(f)
+            if wh.prime != BN254_R:
+                raise ValueError("different wtns curve")             # main_prover.cpp:53-55
+            if wh.nVars != self.header.nVars:
+                raise ValueError("wtns has %d variables, zkey expects %d" % (wh.nVars, self.header.nVars))   # quirk Q8
+            vals = f.getSectionData(2)
+        else:
+            vals = wtns
+        a = np.frombuffer(vals, dtype=np.uint8)
+        if a.size != self.header.nVars * 32:
+            raise ValueError("witness size mismatch")
+        return a
+
+    def prove(self, wtns, r=None, s=None):
+        """-> 256 proof bytes (A|B|C affine Montgomery, == Proof<Engine>)."""
+        a = self._wtns_values(wtns)
+        (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
+        out = L.zk_proof()
+        L.check(self._lib.zk_prove(self._h, C.c_void_p(a.ctypes.data), rp, sp, C.byref(out)))
+        return bytes(out)
+
+    def prove_dev(self, d_wtns_ptr, r=None, s=None):
+        (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
+        out = L.zk_proof()
+        L.check(self._lib.zk_prove_dev(self._h, C.c_void_p(d_wtns_ptr), rp, sp, C.byref(out)))
+        return bytes(out)
+
+    def prove_msm(self, wtns):
+        a = self._wtns_values(wtns)
+        out = L.zk_msm_sums()
+        L.check(self._lib.zk_prove_msm(self._h, C.c_void_p(a.ctypes.data), C.byref(out)))
+        return bytes(out)
+
+    def prove_msm_dev(self, d_wtns_ptr):
+        out = L.zk_msm_sums()
+        L.check(self._lib.zk_prove_msm_dev(self._h, C.c_void_p(d_wtns_ptr), C.byref(out)))
+        return bytes(out)
+
+    def prove_finish(self, partials, r=None, s=None):
+        arr = (L.zk_msm_sums * len(partials))(*[L.zk_msm_sums.from_buffer_copy(p) for p in partials])
+        (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
+        out = L.zk_proof()
+        L.check(self._lib.zk_prove_finish(self._h, arr, len(partials), rp, sp, C.byref(out)))
+        return bytes(out)
+
+    def timings(self):
+        ms = (C.c_double * len(L.ZK_T_NAMES))()
+        L.check(self._lib.zk_prover_timings(self._h, ms, len(L.ZK_T_NAMES)))
+        return dict(zip(L.ZK_T_NAMES, list(ms)))
+
+
+def prove_files(zkey_path, wtns_path, proof_path, public_path, r=None, s=None):
+    """`prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>` (main_prover.cpp:23-103)."""
+    p = Prover(zkey_path)
+    try:
+        vals = p._wtns_values(wtns_path)
+        proof = p.prove(vals, r, s)
+        with open(proof_path, "w") as f:
+            f.write(L.proof_to_json(proof))
+        with open(public_path, "w") as f:
+            f.write(L.public_to_json(vals, p.header.nPublic))
+    finally:
+        p.close()
