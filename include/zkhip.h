@@ -122,6 +122,14 @@ int zk_fr_abc_to_h(uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n);
 int zk_msm_g1(uint8_t out[64], const uint8_t *bases, const uint8_t *scalars, uint64_t n);
 int zk_msm_g2(uint8_t out[128], const uint8_t *bases, const uint8_t *scalars, uint64_t n);
 
+/* ---- synthetic tables & single-point helpers (benchmark inputs) ------ */
+/* out[i] = P0 + i*Q, affine Montgomery, generated on the GPU (host output buffer). */
+int zk_synth_chain_g1(uint8_t *out, uint64_t n, const uint8_t p0[64], const uint8_t q[64]);
+int zk_synth_chain_g2(uint8_t *out, uint64_t n, const uint8_t p0[128], const uint8_t q[128]);
+/* out = k*P — Curve::mulByScalar (src/groth16.cpp:223) on the host; k: 32 B LE standard form. */
+int zk_g1_mul(uint8_t out[64], const uint8_t p[64], const uint8_t k[32]);
+int zk_g2_mul(uint8_t out[128], const uint8_t p[128], const uint8_t k[32]);
+
 /* ---- output formatting (src/groth16.cpp:268-301, src/main_prover.cpp:77-93) - */
 /* Compact JSON exactly as nlohmann's operator<< prints Proof::toJson(); returns needed length
  * (excluding NUL); writes at most cap bytes incl. NUL. */

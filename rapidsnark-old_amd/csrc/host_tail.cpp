@@ -160,6 +160,23 @@ static size_t emit(const std::string &s, char *buf, size_t cap) {
     return s.size();
 }
 
+int zk_g1_mul(uint8_t out[64], const uint8_t p[64], const uint8_t k[32]) {
+    zk::u32 kk[8];
+    memcpy(kk, k, 32);
+    zk::G1A a = zk::load<zk::G1A>(p);
+    zk::G1A r = zk::to_affine(zk::scalar_mul(zk::G1P::from_affine(a), kk));
+    memcpy(out, &r, 64);
+    return 0;
+}
+int zk_g2_mul(uint8_t out[128], const uint8_t p[128], const uint8_t k[32]) {
+    zk::u32 kk[8];
+    memcpy(kk, k, 32);
+    zk::G2A a = zk::load<zk::G2A>(p);
+    zk::G2A r = zk::to_affine(zk::scalar_mul(zk::G2P::from_affine(a), kk));
+    memcpy(out, &r, 128);
+    return 0;
+}
+
 size_t zk_proof_to_json(const zk_proof *p, char *buf, size_t cap) {
     // Key order / spacing of nlohmann's compact dump of Proof::toJson
     auto d = [](const uint8_t *b) { return zk::HostTail::fq_mont_to_dec(b); };

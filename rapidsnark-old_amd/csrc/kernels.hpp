@@ -58,15 +58,23 @@ void launch_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p
 void launch_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total_buckets, hipStream_t s);
 // entries[cursor[bucket]++] = idx | sign<<31
 void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
-// buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min
+// buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min.
+// max_entries: upper bound of offsets[total_buckets] (= n*W); ws_*: msm_accum_workspace_slots() slots.
+uint64_t msm_accum_workspace_slots(uint64_t max_entries);
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, hipStream_t s);
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
+                         G1XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s);
 void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, hipStream_t s);
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
+                         G2XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s);
 // window_sums[m*W + w] = sum_k (k+1) * buckets[m][w][k]  for n_msm bucket arrays laid back to back;
 // scratch: n_msm * W * nbuckets/REDUCE_CHUNK points
 void launch_msm_reduce_g1(G1XYZZ *window_sums, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 void launch_msm_reduce_g2(G2XYZZ *window_sums, G2XYZZ *scratch, const G2XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p);
+
+// ---------------------------------------------------------------- synth.hip
+void launch_chain_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &P0, const G1Affine &Q, uint64_t n, hipStream_t s);
+void launch_chain_g2(G2Affine *d_out, G2XYZZ *d_tmp, Fq2 *d_pref, const G2Affine &P0, const G2Affine &Q, uint64_t n, hipStream_t s);
 
 }   // namespace zk

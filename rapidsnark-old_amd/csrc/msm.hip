@@ -7,8 +7,9 @@
 //   3. k_msm_scatter : counting sort of (point index | sign) into bucket order
 //      (1-3 run ONCE per scalar vector: the witness sort is shared by MSM A, B1, B2, C,
 //       which the reference recomputes four times, src/groth16.cpp:183-204)
-//   4. k_msm_accum   : one lane per bucket walks its sorted run and mixed-adds the gathered
-//      affine points into an XYZZ accumulator kept in VGPRs (next point prefetched)
+//   4. k_msm_accum_l1/_ln : load-balanced segmented accumulation — every lane mixed-adds a
+//      fixed-size chunk of the bucket-sorted list into XYZZ accumulators in VGPRs (next point
+//      prefetched); runs cut by chunk edges are merged by recursively shrinking levels
 //   5. k_msm_reduce_chunks / k_msm_reduce_final : sum_k (k+1)*B_k per window via chunked
 //      running sums + an LDS tree
 //   6. host: Horner over the W window sums (host_tail.cpp) — 256 serial doublings are
@@ -161,36 +162,135 @@ __global__ __launch_bounds__(1024) void k_msm_scan(uint32_t *offsets, uint32_t *
     if (tid == 1023) offsets[total] = sums[1023];
 }
 
-// One lane per bucket.  Adjacent lanes own adjacent buckets of one window, so run lengths
-// within a wave are similar (Poisson around n/2^(c-1)) and divergence stays at the tail.
+// ---------------------------------------------------------------- load-balanced accumulation
+// A lane-per-bucket walk is hopeless on real data: the top window of uniformly random
+// scalars has only a handful of non-empty buckets (r ~ 2^253.6), and real witnesses pile
+// half their entries into bucket "1" of window 0.  Instead EVERY lane adds exactly
+// ACC_CHUNK consecutive entries of the bucket-sorted list, whatever buckets they span:
+//   * a bucket run that starts and ends inside the chunk is complete -> buckets[b];
+//   * a run cut by the chunk's left edge goes to the lane's HEAD slot, one cut by the right
+//     edge to its TAIL slot (at most one of each), tagged with its bucket and STARTS/ENDS flags;
+//   * the slot list (2 per lane, still bucket-sorted) is reduced by the same algorithm with
+//     XYZZ inputs (k_msm_accum_ln), shrinking ~ACC_CHUNK_N/2 per level until one lane is left.
+// Work per lane is constant, so the kernel time is flat in the scalar distribution.
+#define ACC_CHUNK 128u      // affine points per lane, level 1
+#define ACC_CHUNK_N 32u     // slots per lane, levels >= 2
+#define SLOT_EMPTY 0xffffffffu
+#define FLAG_STARTS 1u
+#define FLAG_ENDS 2u
+
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries,
-                                                   const Affine<F> *points, uint32_t idx_min, uint32_t idx_sub, uint32_t total) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= total) return;
-    uint32_t e = offsets[b];
-    const uint32_t end = offsets[b + 1];
-    XYZZ<F> acc = XYZZ<F>::inf();
-    // software prefetch: the next point's 64/128 bytes are in flight while this one is added
-    Affine<F> nextP = Affine<F>::inf();
-    bool nextNeg = false;
-    auto fetch = [&](uint32_t pos) {
-        uint32_t ent = entries[pos];
-        uint32_t idx = ent & 0x7fffffffu;
-        nextNeg = (ent >> 31) != 0;
-        if (idx >= idx_min) nextP = load_affine(points + (idx - idx_sub));
-        else nextP = Affine<F>::inf();
-    };
-    if (e < end) fetch(e);
-    while (e < end) {
-        Affine<F> P = nextP;
-        bool ng = nextNeg;
-        e++;
-        if (e < end) fetch(e);
-        if (ng) P.y = F::neg(P.y);
-        madd(acc, P);
+__global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries,
+                                                      const Affine<F> *points, uint32_t idx_min, uint32_t idx_sub,
+                                                      uint32_t nbuckets_total, XYZZ<F> *out_part, uint32_t *out_key,
+                                                      uint32_t *out_flag, uint32_t nlanes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlanes) return;
+    const uint32_t E = offsets[nbuckets_total];
+    const uint64_t lo64 = (uint64_t)t * ACC_CHUNK;
+    uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
+    if (lo64 < E) {
+        const uint32_t lo = (uint32_t)lo64;
+        const uint32_t hi = (E - lo > ACC_CHUNK) ? lo + ACC_CHUNK : E;
+        // last b with offsets[b] <= lo  (skips empty buckets that share the same offset)
+        uint32_t bl = 0, br = nbuckets_total - 1;
+        while (bl < br) {
+            uint32_t mid = (bl + br + 1) >> 1;
+            if (offsets[mid] <= lo) bl = mid; else br = mid - 1;
+        }
+        uint32_t b = bl;
+        uint32_t bend = offsets[b + 1];
+        bool started_before = offsets[b] < lo;
+        XYZZ<F> acc = XYZZ<F>::inf();
+        Affine<F> nextP = Affine<F>::inf();
+        bool nextNeg = false;
+        auto fetch = [&](uint32_t pos) {
+            uint32_t ent = entries[pos];
+            uint32_t idx = ent & 0x7fffffffu;
+            nextNeg = (ent >> 31) != 0;
+            if (idx >= idx_min) nextP = load_affine(points + (idx - idx_sub));
+            else nextP = Affine<F>::inf();
+        };
+        uint32_t e = lo;
+        fetch(e);
+        while (e < hi) {
+            Affine<F> P = nextP;
+            bool ng = nextNeg;
+            e++;
+            if (e < hi) fetch(e);
+            if (ng) P.y = F::neg(P.y);
+            madd(acc, P);
+            if (e == bend || e == hi) {              // the run of bucket b ends here (or is cut)
+                const bool ends = (e == bend);
+                if (!started_before && ends) {
+                    store_xyzz(buckets + b, acc);
+                } else if (started_before) {
+                    store_xyzz(out_part + 2 * (uint64_t)t, acc);
+                    hkey = b;
+                    hflag = ends ? FLAG_ENDS : 0u;
+                } else {
+                    store_xyzz(out_part + 2 * (uint64_t)t + 1, acc);
+                    tkey = b;
+                    tflag = FLAG_STARTS;
+                }
+                if (e < hi) {                        // next non-empty bucket
+                    do { b++; bend = offsets[b + 1]; } while (bend == e);
+                    started_before = false;
+                    acc = XYZZ<F>::inf();
+                }
+            }
+        }
     }
-    store_xyzz(buckets + b, acc);
+    out_key[2 * (uint64_t)t] = hkey;
+    out_flag[2 * (uint64_t)t] = hflag;
+    out_key[2 * (uint64_t)t + 1] = tkey;
+    out_flag[2 * (uint64_t)t + 1] = tflag;
+}
+
+// Levels >= 2: the same chunked segmented sum over a bucket-sorted slot list of XYZZ partials.
+template <class F>
+__global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XYZZ<F> *in_part, const uint32_t *in_key,
+                                                      const uint32_t *in_flag, uint32_t nitems, XYZZ<F> *out_part,
+                                                      uint32_t *out_key, uint32_t *out_flag, uint32_t nlanes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlanes) return;
+    const uint32_t lo = t * ACC_CHUNK_N;
+    const uint32_t hi = lo + ACC_CHUNK_N < nitems ? lo + ACC_CHUNK_N : nitems;
+    uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
+    uint32_t cur = SLOT_EMPTY, cflag = 0;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    auto flush = [&]() {
+        if (cur == SLOT_EMPTY) return;
+        if ((cflag & FLAG_STARTS) && (cflag & FLAG_ENDS)) {
+            store_xyzz(buckets + cur, acc);
+        } else if (!(cflag & FLAG_STARTS)) {         // continues a bucket begun in an earlier lane
+            store_xyzz(out_part + 2 * (uint64_t)t, acc);
+            hkey = cur;
+            hflag = cflag & FLAG_ENDS;
+        } else {                                     // starts here, continues in a later lane
+            store_xyzz(out_part + 2 * (uint64_t)t + 1, acc);
+            tkey = cur;
+            tflag = FLAG_STARTS;
+        }
+    };
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t k = in_key[i];
+        if (k == SLOT_EMPTY) continue;
+        uint32_t fl = in_flag[i];
+        if (k != cur) {
+            flush();
+            cur = k;
+            cflag = fl & FLAG_STARTS;
+            acc = XYZZ<F>::inf();
+        }
+        cflag = (cflag & FLAG_STARTS) | (fl & FLAG_ENDS);
+        add(acc, load_xyzz(in_part + i));
+    }
+    flush();
+    out_key[2 * (uint64_t)t] = hkey;
+    out_flag[2 * (uint64_t)t] = hflag;
+    out_key[2 * (uint64_t)t + 1] = tkey;
+    out_flag[2 * (uint64_t)t + 1] = tflag;
 }
 
 // Lane per chunk of REDUCE_CHUNK buckets: running sums give A = sum (j+1)*B[lo+j], T = sum B;
@@ -264,13 +364,50 @@ void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, 
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_msm_scatter, dim3((uint32_t)g), dim3(256), 0, s, entries, cursor, scalars, n, p);
 }
+// workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
+static inline uint64_t accum_l1_lanes(uint64_t max_entries) { return (max_entries + ACC_CHUNK - 1) / ACC_CHUNK; }
+uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
+    uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
+    uint64_t total = 0;
+    for (;;) {
+        uint64_t slots = 2 * lanes;
+        total += slots;
+        if (lanes == 1) break;
+        lanes = (slots + ACC_CHUNK_N - 1) / ACC_CHUNK_N;
+    }
+    return total;
+}
+
+template <class F>
+static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries, const Affine<F> *points,
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
+                         XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s) {
+    // empty buckets are never written by the kernels: infinity is the all-zero pattern
+    (void)hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s);
+    uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
+    hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
+                       points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes);
+    uint64_t off = 0;
+    while (lanes > 1) {          // a single lane has no cut runs: everything it saw was complete
+        uint64_t items = 2 * lanes;
+        uint64_t nl = (items + ACC_CHUNK_N - 1) / ACC_CHUNK_N;
+        uint64_t noff = off + items;
+        hipLaunchKernelGGL(k_msm_accum_ln<F>, dim3((uint32_t)((nl + 127) / 128)), dim3(128), 0, s, buckets, ws_part + off,
+                           ws_key + off, ws_flag + off, (uint32_t)items, ws_part + noff, ws_key + noff, ws_flag + noff, (uint32_t)nl);
+        off = noff;
+        lanes = nl;
+    }
+}
+
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_accum<Fq>, dim3((total + 255) / 256), dim3(256), 0, s, buckets, offsets, entries, points, idx_min, idx_sub, total);
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G1XYZZ *ws_part,
+                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s) {
+    launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s);
 }
 void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_accum<Fq2>, dim3((total + 255) / 256), dim3(256), 0, s, buckets, offsets, entries, points, idx_min, idx_sub, total);
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2XYZZ *ws_part,
+                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s) {
+    launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s);
 }
 
 template <class F>

@@ -118,8 +118,9 @@ struct zk_prover {
     SortBufs sort_w, sort_h;
     DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
     DevBuf<G2XYZZ> buckets_g2;
-    DevBuf<G1XYZZ> scratch_g1, wsum_g1;
-    DevBuf<G2XYZZ> scratch_g2, wsum_g2;
+    DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1;
+    DevBuf<G2XYZZ> scratch_g2, wsum_g2, acc_ws_g2;
+    DevBuf<uint32_t> acc_key, acc_flag;
 
     hipEvent_t ev[10];
     bool have_events = false;
@@ -292,6 +293,12 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->wsum_g1.alloc(3 * p->sort_w.plan.W + p->sort_h.plan.W);
         p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
         p->wsum_g2.alloc(p->sort_w.plan.W);
+        uint64_t ew = (uint64_t)(nv ? nv : 1) * p->sort_w.plan.W, eh = (uint64_t)(nh ? nh : 1) * p->sort_h.plan.W;
+        uint64_t slots = msm_accum_workspace_slots(ew > eh ? ew : eh);
+        p->acc_ws_g1.alloc(slots);
+        p->acc_ws_g2.alloc(msm_accum_workspace_slots(ew));
+        p->acc_key.alloc(slots);
+        p->acc_flag.alloc(slots);
     }
     for (auto &e : p->ev) HIP_TRY(hipEventCreate(&e));
     p->have_events = true;
@@ -331,12 +338,13 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     // 6-10: bucket accumulation
     const uint32_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
     G1XYZZ *bA = p->buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
-    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, s);
-    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, s);
-    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, s);
-    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, s);
+    const uint64_t ew = p->sort_w.n * p->sort_w.plan.W, eh = p->sort_h.n * p->sort_h.plan.W;
+    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
+    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
+    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
+    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
     mark(4);
-    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, s);
+    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key.p, p->acc_flag.p, s);
     mark(5);
     // bucket reduction -> window sums
     const uint32_t Ww = p->sort_w.plan.W, Wh = p->sort_h.plan.W;
@@ -590,16 +598,21 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     SortBufs sb;
     sb.alloc(n, 0);
     sb.run(sc.p, 0);
-    DevBuf<XT> buckets, scratch, wsum;
+    DevBuf<XT> buckets, scratch, wsum, ws;
+    DevBuf<uint32_t> wkey, wflag;
+    const uint64_t emax = n * sb.plan.W, slots = msm_accum_workspace_slots(emax);
+    ws.alloc(slots);
+    wkey.alloc(slots);
+    wflag.alloc(slots);
     buckets.alloc(sb.total_buckets());
     scratch.alloc(msm_reduce_scratch_points(1, sb.plan));
     wsum.alloc(sb.plan.W);
     std::vector<uint8_t> w((size_t)sb.plan.W * sizeof(XT));
     if constexpr (sizeof(AffT) == 64) {
-        launch_msm_accum_g1((G1XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), 0);
+        launch_msm_accum_g1((G1XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G1XYZZ *)ws.p, wkey.p, wflag.p, 0);
         launch_msm_reduce_g1((G1XYZZ *)wsum.p, (G1XYZZ *)scratch.p, (const G1XYZZ *)buckets.p, 1, sb.plan, 0);
     } else {
-        launch_msm_accum_g2((G2XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G2Affine *)pts.p, 0, 0, sb.total_buckets(), 0);
+        launch_msm_accum_g2((G2XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G2Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G2XYZZ *)ws.p, wkey.p, wflag.p, 0);
         launch_msm_reduce_g2((G2XYZZ *)wsum.p, (G2XYZZ *)scratch.p, (const G2XYZZ *)buckets.p, 1, sb.plan, 0);
     }
     HIP_TRY(hipMemcpy(w.data(), wsum.p, w.size(), hipMemcpyDeviceToHost));
@@ -607,7 +620,32 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     else HostTail::combine_windows_g1(w.data(), sb.plan.W, sb.plan.c, out);
 }
 
+template <class AffT, class XT, class FT>
+static void synth_chain(uint8_t *out, uint64_t n, const uint8_t *p0, const uint8_t *q,
+                        void (*launch)(AffT *, XT *, FT *, const AffT &, const AffT &, uint64_t, hipStream_t)) {
+    need_device();
+    if (!n) return;
+    DevBuf<AffT> d_out;
+    DevBuf<XT> d_tmp;
+    DevBuf<FT> d_pref;
+    d_out.alloc(n);
+    d_tmp.alloc(n);
+    d_pref.alloc(n);
+    AffT P0, Q;
+    memcpy(&P0, p0, sizeof(AffT));
+    memcpy(&Q, q, sizeof(AffT));
+    launch(d_out.p, d_tmp.p, d_pref.p, P0, Q, n, 0);
+    HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(AffT), hipMemcpyDeviceToHost));
+}
+
 extern "C" {
+
+int zk_synth_chain_g1(uint8_t *out, uint64_t n, const uint8_t p0[64], const uint8_t q[64]) {
+    return guarded([&] { synth_chain<G1Affine, G1XYZZ, Fq>(out, n, p0, q, launch_chain_g1); });
+}
+int zk_synth_chain_g2(uint8_t *out, uint64_t n, const uint8_t p0[128], const uint8_t q[128]) {
+    return guarded([&] { synth_chain<G2Affine, G2XYZZ, Fq2>(out, n, p0, q, launch_chain_g2); });
+}
 
 int zk_msm_g1(uint8_t out[64], const uint8_t *bases, const uint8_t *scalars, uint64_t n) {
     return guarded([&] { msm_generic<G1Affine, G1XYZZ>(out, bases, scalars, n, false); });

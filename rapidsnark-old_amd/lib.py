@@ -48,7 +48,7 @@ ZK_T_NAMES = ["spmv", "ntt", "digits_sort", "msm_g1_accum", "msm_g2_accum", "msm
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
            "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
-           "zk_public_to_json"]
+           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_g1_mul", "zk_g2_mul"]
 
 
 def load_library():
@@ -59,6 +59,12 @@ def load_library():
     if not os.path.exists(path):
         raise ZkHipError("libzkhip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C rapidsnark-old_amd/csrc`; there is no CPU fallback" % path)
+    try:
+        # torch wheels bundle their own libamdhip64; load it FIRST so this process holds ONE HIP
+        # runtime (two runtimes => the second one sees "No HIP GPUs are available").
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.zk_last_error.restype = C.c_char_p
     u8p = C.c_void_p
@@ -78,6 +84,10 @@ def load_library():
     lib.zk_fr_abc_to_h.argtypes = [u8p, u8p, u8p, C.c_uint64]
     lib.zk_msm_g1.argtypes = [u8p, u8p, u8p, C.c_uint64]
     lib.zk_msm_g2.argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_synth_chain_g1.argtypes = [u8p, C.c_uint64, u8p, u8p]
+    lib.zk_synth_chain_g2.argtypes = [u8p, C.c_uint64, u8p, u8p]
+    lib.zk_g1_mul.argtypes = [u8p, u8p, u8p]
+    lib.zk_g2_mul.argtypes = [u8p, u8p, u8p]
     lib.zk_proof_to_json.argtypes = [C.POINTER(zk_proof), C.c_char_p, C.c_size_t]
     lib.zk_proof_to_json.restype = C.c_size_t
     lib.zk_public_to_json.argtypes = [u8p, C.c_uint32, C.c_char_p, C.c_size_t]
@@ -172,3 +182,33 @@ def public_to_json(wtns_values_bytes, n_public):
     buf = C.create_string_buffer(n + 1)
     lib.zk_public_to_json(_ptr(a), n_public, buf, n + 1)
     return buf.value.decode()
+
+
+def synth_chain_g1(n, p0, q):
+    """out[i] = P0 + i*Q on the GPU -> numpy uint8 [n*64] (affine Montgomery)."""
+    out = np.zeros(n * 64, dtype=np.uint8)
+    a, b = _buf(p0).copy(), _buf(q).copy()
+    check(load_library().zk_synth_chain_g1(_ptr(out), n, _ptr(a), _ptr(b)))
+    return out
+
+
+def synth_chain_g2(n, p0, q):
+    out = np.zeros(n * 128, dtype=np.uint8)
+    a, b = _buf(p0).copy(), _buf(q).copy()
+    check(load_library().zk_synth_chain_g2(_ptr(out), n, _ptr(a), _ptr(b)))
+    return out
+
+
+def g1_mul(p, k):
+    """k*P on the host (product code, 64-bit limbs): Curve::mulByScalar."""
+    out = np.zeros(64, dtype=np.uint8)
+    a, kk = _buf(p).copy(), np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    check(load_library().zk_g1_mul(_ptr(out), _ptr(a), _ptr(kk)))
+    return out.tobytes()
+
+
+def g2_mul(p, k):
+    out = np.zeros(128, dtype=np.uint8)
+    a, kk = _buf(p).copy(), np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    check(load_library().zk_g2_mul(_ptr(out), _ptr(a), _ptr(kk)))
+    return out.tobytes()
