@@ -99,6 +99,12 @@ int zk_prove_msm(zk_prover *p, const uint8_t *wtns, zk_msm_sums *partial);
 int zk_prove_finish(zk_prover *p, const zk_msm_sums *partials, uint32_t n_partials,
                     const uint8_t *r32, const uint8_t *s32, zk_proof *out);
 
+/* Same as zk_prove_finish without a prover object: pure host code, usable on a rank that owns
+ * no GPU (e.g. a coordinator).  vk points as in zk_zkey_view. */
+int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta2, const void *vk_delta1,
+                const void *vk_delta2, const zk_msm_sums *partials, uint32_t n_partials,
+                const uint8_t *r32, const uint8_t *s32, zk_proof *out);
+
 /* Per-stage device times of the last prove, ms (needs ZK_FLAG_TIMINGS).  Order: see ZK_T_*. */
 enum {
     ZK_T_SPMV = 0, ZK_T_NTT, ZK_T_DIGITS_SORT, ZK_T_MSM_G1_ACCUM, ZK_T_MSM_G2_ACCUM,

@@ -7,6 +7,7 @@
 
 #include <string.h>
 #include <stdio.h>
+#include <sys/random.h>
 #include <vector>
 
 namespace zk {
@@ -174,6 +175,42 @@ int zk_g2_mul(uint8_t out[128], const uint8_t p[128], const uint8_t k[32]) {
     zk::G2A a = zk::load<zk::G2A>(p);
     zk::G2A r = zk::to_affine(zk::scalar_mul(zk::G2P::from_affine(a), kk));
     memcpy(out, &r, 128);
+    return 0;
+}
+
+static int draw31(uint8_t out[32]) {
+    // src/groth16.cpp:213-217: zero, then 31 random bytes into the low bytes
+    memset(out, 0, 32);
+    size_t got = 0;
+    while (got < 31) {
+        ssize_t k = getrandom(out + got, 31 - got, 0);
+        if (k < 0) return -1;
+        got += (size_t)k;
+    }
+    return 0;
+}
+
+int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta2, const void *vk_delta1,
+                const void *vk_delta2, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32,
+                const uint8_t *s32, zk_proof *out) {
+    if (!vk_alpha1 || !vk_beta1 || !vk_beta2 || !vk_delta1 || !vk_delta2 || !parts || !out || !nparts) {
+        zk::set_error("zk_assemble: null argument or no partial sums");
+        return 1;
+    }
+    zk_msm_sums t = parts[0];
+    for (uint32_t i = 1; i < nparts; i++) {
+        zk::HostTail::add_affine_g1(t.pih, parts[i].pih);
+        zk::HostTail::add_affine_g1(t.pi_a, parts[i].pi_a);
+        zk::HostTail::add_affine_g1(t.pib1, parts[i].pib1);
+        zk::HostTail::add_affine_g2(t.pi_b, parts[i].pi_b);
+        zk::HostTail::add_affine_g1(t.pi_c, parts[i].pi_c);
+    }
+    uint8_t r[32], s[32];
+    if (r32) memcpy(r, r32, 32); else if (draw31(r)) { zk::set_error("getrandom failed"); return 1; }
+    if (s32) memcpy(s, s32, 32); else if (draw31(s)) { zk::set_error("getrandom failed"); return 1; }
+    zk::HostTail::final_assembly((const uint8_t *)vk_alpha1, (const uint8_t *)vk_beta1, (const uint8_t *)vk_beta2,
+                                 (const uint8_t *)vk_delta1, (const uint8_t *)vk_delta2, t.pih, t.pi_a, t.pib1, t.pi_b,
+                                 t.pi_c, r, s, out->A, out->B, out->C);
     return 0;
 }
 

@@ -379,32 +379,9 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     HostTail::combine_windows_g2(w2.data(), Ww, cw, out->pi_b);
 }
 
-void draw_rs(uint8_t out[32]) {
-    // src/groth16.cpp:213-217: zero, then 31 random bytes into the low bytes
-    memset(out, 0, 32);
-    size_t got = 0;
-    while (got < 31) {
-        ssize_t k = getrandom(out + got, 31 - got, 0);
-        if (k < 0) throw std::runtime_error("getrandom failed");
-        got += (size_t)k;
-    }
-}
-
 void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
-    if (!nparts) throw std::invalid_argument("no partial sums");
-    zk_msm_sums t = parts[0];
-    for (uint32_t i = 1; i < nparts; i++) {
-        HostTail::add_affine_g1(t.pih, parts[i].pih);
-        HostTail::add_affine_g1(t.pi_a, parts[i].pi_a);
-        HostTail::add_affine_g1(t.pib1, parts[i].pib1);
-        HostTail::add_affine_g2(t.pi_b, parts[i].pi_b);
-        HostTail::add_affine_g1(t.pi_c, parts[i].pi_c);
-    }
-    uint8_t r[32], s[32];
-    if (r32) memcpy(r, r32, 32); else draw_rs(r);
-    if (s32) memcpy(s, s32, 32); else draw_rs(s);
-    HostTail::final_assembly(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, t.pih, t.pi_a, t.pib1,
-                             t.pi_b, t.pi_c, r, s, out->A, out->B, out->C);
+    if (zk_assemble(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, parts, nparts, r32, s32, out))
+        throw std::runtime_error(get_error());
 }
 
 const Fr *stage_witness(zk_prover *p, const uint8_t *wtns) {

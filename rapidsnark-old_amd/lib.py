@@ -48,7 +48,7 @@ ZK_T_NAMES = ["spmv", "ntt", "digits_sort", "msm_g1_accum", "msm_g2_accum", "msm
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
            "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
-           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_g1_mul", "zk_g2_mul"]
+           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble"]
 
 
 def load_library():
@@ -77,6 +77,7 @@ def load_library():
     lib.zk_prove_msm.argtypes = [C.c_void_p, u8p, C.POINTER(zk_msm_sums)]
     lib.zk_prove_msm_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(zk_msm_sums)]
     lib.zk_prove_finish.argtypes = [C.c_void_p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
+    lib.zk_assemble.argtypes = [u8p, u8p, u8p, u8p, u8p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_prover_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     for name in ("zk_fr_mul_vec", "zk_fq_mul_vec"):
         getattr(lib, name).argtypes = [u8p, u8p, u8p, C.c_uint64]
@@ -212,3 +213,16 @@ def g2_mul(p, k):
     a, kk = _buf(p).copy(), np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
     check(load_library().zk_g2_mul(_ptr(out), _ptr(a), _ptr(kk)))
     return out.tobytes()
+
+
+def assemble(vk, partials, r=None, s=None):
+    """Host-only final assembly (src/groth16.cpp:209-253) over the partial MSM sums of all shards.
+    vk: dict with vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2 (bytes)."""
+    keep = [_buf(vk[k]).copy() for k in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2")]
+    arr = (zk_msm_sums * len(partials))(*[zk_msm_sums.from_buffer_copy(bytes(p)) for p in partials])
+    ra = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8).copy() if r is not None else None
+    sa = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8).copy() if s is not None else None
+    out = zk_proof()
+    check(load_library().zk_assemble(*[_ptr(a) for a in keep], arr, len(partials),
+                                     _ptr(ra) if ra is not None else None, _ptr(sa) if sa is not None else None, C.byref(out)))
+    return bytes(out)

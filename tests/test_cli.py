@@ -1,0 +1,70 @@
+"""The `prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>` executable
+(reference src/main_prover.cpp:23-103): argv, messages, exit codes, output bytes."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import CIRCUITS, ROOT, golden_bytes, golden_json, golden_path
+
+PROVER = os.path.join(ROOT, "rapidsnark-old_amd", "prover")
+
+
+def run(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([PROVER, *args], capture_output=True, text=True, env=e, timeout=300)
+
+
+def test_usage_and_exit_code():
+    r = run()
+    assert r.returncode == 255                                   # `return -1` (main_prover.cpp:28)
+    assert r.stderr == "Invalid number of parameters:\nUsage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>\n"
+    assert run("a", "b", "c").returncode == 255
+
+
+def test_bad_inputs_are_reported_not_aborted(tmp_path):
+    # quirk Q1: the reference throws a pointer here and aborts; we print the same text and exit -1
+    r = run(golden_path("multiplier2", "witness.wtns"), golden_path("multiplier2", "witness.wtns"), str(tmp_path / "p"), str(tmp_path / "q"))
+    assert r.returncode == 255 and r.stderr == "Invalid file type. It should be zkey and it us wtns\n"
+    r = run("/nonexistent.zkey", "x", "y", "z")
+    assert r.returncode == 255 and r.stderr.startswith("open")
+    bad = bytearray(golden_bytes("multiplier2", "circuit.zkey"))
+    bad[4] = 7
+    (tmp_path / "v.zkey").write_bytes(bytes(bad))
+    r = run(str(tmp_path / "v.zkey"), golden_path("multiplier2", "witness.wtns"), str(tmp_path / "p"), str(tmp_path / "q"))
+    assert r.returncode == 255 and r.stderr == "Invalid version. It should be <=1 and it us 7\n"
+    trunc = golden_bytes("multiplier2", "circuit.zkey")[:300]
+    (tmp_path / "t.zkey").write_bytes(trunc)
+    r = run(str(tmp_path / "t.zkey"), golden_path("multiplier2", "witness.wtns"), str(tmp_path / "p"), str(tmp_path / "q"))
+    assert r.returncode == 255 and "end of file" in r.stderr
+    # witness of another circuit: quirk Q8 (OOB read in the reference) is an error here
+    r = run(golden_path("r1cs_n8", "circuit.zkey"), golden_path("multiplier2", "witness.wtns"), str(tmp_path / "p"), str(tmp_path / "q"))
+    assert r.returncode == 255 and "nVars" in r.stderr
+
+
+def _le_hex(x):
+    return int(x).to_bytes(32, "little").hex()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CIRCUITS)
+def test_cli_output_bytes(tmp_path, name):
+    meta = golden_json(name, "meta.json")
+    pj, qj = tmp_path / "proof.json", tmp_path / "public.json"
+    r = run(golden_path(name, "circuit.zkey"), golden_path(name, "witness.wtns"), str(pj), str(qj),
+            env={"ZKHIP_FIXED_R": _le_hex(meta["r"]), "ZKHIP_FIXED_S": _le_hex(meta["s"])})
+    assert r.returncode == 0, r.stderr
+    assert pj.read_bytes() == golden_bytes(name, "proof.json")          # compact, no trailing newline
+    assert qj.read_bytes() == golden_bytes(name, "public.json")
+
+
+@pytest.mark.gpu
+def test_cli_random_rs_differs(tmp_path):
+    outs = []
+    for i in range(2):
+        pj = tmp_path / ("p%d.json" % i)
+        r = run(golden_path("r1cs_n8", "circuit.zkey"), golden_path("r1cs_n8", "witness.wtns"), str(pj), str(tmp_path / "q.json"))
+        assert r.returncode == 0, r.stderr
+        outs.append(pj.read_bytes())
+    assert outs[0] != outs[1]

@@ -1,0 +1,132 @@
+"""CPU: host logic of the product — the binfile/zkey/wtns mirrors, the C-ABI library's export
+list, and the host-only entry points (JSON formatting, point scalar-mul, zk_assemble).
+No compute entry point is called: those need a GPU and must FAIL loudly without one."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import CIRCUITS, ROOT, golden_bytes, golden_json, golden_path
+from oracle import bn254 as bn, groth16_ref as g
+
+
+def test_library_exports_every_symbol_of_the_header(zk):
+    hdr = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+    declared = set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", hdr))
+    from rapidsnark_old_amd import lib as L
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = ctypes.CDLL(zk.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu(zk):
+    try:
+        n = zk.device_count()
+    except zk.ZkHipError:
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(zk.ZkHipError):
+        zk.fr_mul_vec(bytes(32), bytes(32))
+    with pytest.raises(zk.ZkHipError):
+        zk.msm_g1(bytes(64), bytes(32))
+    with pytest.raises(zk.ZkHipError):
+        zk.Prover(golden_path("multiplier2", "circuit.zkey"))
+
+
+@pytest.mark.parametrize("name", CIRCUITS)
+def test_host_json_matches_golden(zk, name):
+    meta = golden_json(name, "meta.json")
+    assert zk.proof_to_json(bytes.fromhex(meta["proof_bytes"])) == golden_bytes(name, "proof.json").decode()
+    wt = g.read_wtns(golden_bytes(name, "witness.wtns"))
+    vals = b"".join(bn.int_to_le32(v) for v in wt["witness"])
+    f = zk.open_existing(golden_path(name, "circuit.zkey"), "zkey", 1)
+    h = zk.load_zkey_header(f)
+    assert zk.public_to_json(vals, h.nPublic) == golden_bytes(name, "public.json").decode()
+
+
+def test_public_json_null_quirk(zk):
+    assert zk.public_to_json(bn.int_to_le32(1), 0) == "null"          # main_prover.cpp:85-92 (Q7)
+    assert zk.public_to_json(bn.int_to_le32(1) + bn.int_to_le32(0), 1) == '["0"]'
+
+
+def test_host_point_mul(zk):
+    g1, g2 = bn.g1_to_bytes(bn.G1.gen), bn.g2_to_bytes(bn.G2.gen)
+    for k in (0, 1, 2, 12345678901234567890, bn.R_MOD - 1, bn.R_MOD):
+        assert zk.g1_mul(g1, k) == bn.g1_to_bytes(bn.G1.mul(bn.G1.gen, k))
+    assert zk.g2_mul(g2, 987654321) == bn.g2_to_bytes(bn.G2.mul(bn.G2.gen, 987654321))
+    assert zk.g1_mul(bytes(64), 5) == bytes(64)
+
+
+@pytest.mark.parametrize("name", CIRCUITS)
+def test_assemble_from_golden_msm_sums(zk, name):
+    """zk_assemble = src/groth16.cpp:209-253 on the host: five MSM results -> proof bytes."""
+    meta = golden_json(name, "meta.json")
+    f = zk.open_existing(golden_path(name, "circuit.zkey"), "zkey", 1)
+    h = zk.load_zkey_header(f)
+    vk = {k: getattr(h, k) for k in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2")}
+    sums = bytes.fromhex(meta["pih"] + meta["pi_a"] + meta["pib1"] + meta["pi_b"] + meta["pi_c"])
+    assert zk.assemble(vk, [sums], int(meta["r"]), int(meta["s"])).hex() == meta["proof_bytes"]
+    a, b = zk.assemble(vk, [sums]), zk.assemble(vk, [sums])              # random r,s: 31 bytes each
+    assert a != b
+
+
+def test_binfile_mirror(zk):
+    data = golden_bytes("r1cs_n8", "circuit.zkey")
+    f = zk.open_existing(data, "zkey", 1)
+    h = zk.load_zkey_header(f)
+    ref = g.read_zkey(data)
+    assert (h.nVars, h.nPublic, h.domainSize, h.nCoefs) == (ref.nVars, ref.nPublic, ref.domainSize, len(ref.coefs))
+    assert h.qPrime == bn.Q_MOD and h.rPrime == bn.R_MOD and h.n8q == 32 and h.n8r == 32
+    assert f.getSectionSize(5) == ref.nVars * 64 and f.getSectionSize(7) == ref.nVars * 128
+    assert f.getSectionSize(8) == (ref.nVars - ref.nPublic - 1) * 64 and f.getSectionSize(9) == ref.domainSize * 64
+    assert bytes(f.getSectionData(5)[:64]) == bn.g1_to_bytes(ref.A[0])
+    w = zk.open_existing(golden_bytes("r1cs_n8", "witness.wtns"), "wtns", 2)
+    wh = zk.load_wtns_header(w)
+    assert wh.n8 == 32 and wh.prime == bn.R_MOD and wh.nVars == ref.nVars
+    # error behaviour (same texts as binfile_utils.cpp:37-44,72-82; thrown by value — quirk Q1 fixed)
+    with pytest.raises(ValueError, match="Invalid file type. It should be zkey"):
+        zk.open_existing(golden_bytes("r1cs_n8", "witness.wtns"), "zkey", 1)
+    bad = bytearray(data)
+    bad[4] = 9
+    with pytest.raises(ValueError, match="Invalid version"):
+        zk.open_existing(bytes(bad), "zkey", 1)
+    with pytest.raises(IndexError, match="Section does not exist"):
+        f.getSectionData(77)
+    f.startReadSection(1)
+    with pytest.raises(IndexError, match="Already reading"):
+        f.startReadSection(2)
+    f.readU32LE()
+    f.endReadSection()
+    f.startReadSection(2)
+    with pytest.raises(IndexError, match="Invalid section size"):
+        f.endReadSection()
+
+
+def test_zkey_not_groth16_is_rejected(zk):
+    data = bytearray(golden_bytes("multiplier2", "circuit.zkey"))
+    f = zk.open_existing(bytes(data), "zkey", 1)
+    off = f.sections[1][0][0]
+    data[off] = 2                                   # protocol id != 1
+    with pytest.raises(ValueError, match="zkey file is not groth16"):
+        zk.load_zkey_header(zk.open_existing(bytes(data), "zkey", 1))
+
+
+def test_synthetic_family_definition(zk):
+    import numpy as np
+    from rapidsnark_old_amd import synth
+    k = 8
+    img = synth.make_coefs(k, 1, 0)
+    n = 1 << k
+    ncoefs = int(np.frombuffer(img[:4].tobytes(), dtype="<u4")[0])
+    assert ncoefs == 4 * (n - 2) + 2 and img.size == 4 + 44 * ncoefs
+    rec = np.frombuffer(img[4:].tobytes(), dtype=synth.COEF_DTYPE)
+    assert set(np.unique(rec["m"])) == {0, 1} and rec["c"].max() == n - 1 and rec["s"].max() < n
+    w = synth.make_witness(k)
+    vals = [int.from_bytes(w[i * 32:(i + 1) * 32].tobytes(), "little") for i in range(n)]
+    assert vals[0] == 1 and max(vals) < bn.R_MOD and len(set(vals)) > n - 3
+    s0, s1 = synth.weighted_sums(w)
+    assert s0 == sum(vals) and s1 == sum(i * v for i, v in enumerate(vals))
+    assert synth.g1_gen_bytes() == bn.g1_to_bytes(bn.G1.gen) and synth.g2_gen_bytes() == bn.g2_to_bytes(bn.G2.gen)
