@@ -20,6 +20,7 @@ struct Fp2T {
     ZK_HD static Fp2T zero() { return Fp2T{B::zero(), B::zero()}; }
     ZK_HD static Fp2T one() { return Fp2T{B::one(), B::zero()}; }
     ZK_HD bool is_zero() const { return a.is_zero() && b.is_zero(); }
+    ZK_HD bool is_zero_raw() const { return a.is_zero_raw() && b.is_zero_raw(); }
     ZK_HD bool operator==(const Fp2T &o) const { return a == o.a && b == o.b; }
     ZK_HD bool operator!=(const Fp2T &o) const { return !(*this == o); }
     ZK_HD static Fp2T add(const Fp2T &x, const Fp2T &y) { return Fp2T{B::add(x.a, y.a), B::add(x.b, y.b)}; }
@@ -47,14 +48,14 @@ typedef Fp2T<Fq> Fq2;
 template <class F>
 struct Affine {
     F x, y;
-    ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    ZK_HD bool is_inf() const { return x.is_zero_raw() && y.is_zero_raw(); }   // all-zero encoding
     ZK_HD static Affine inf() { return Affine{F::zero(), F::zero()}; }
 };
 
 template <class F>
 struct XYZZ {
     F x, y, zz, zzz;
-    ZK_HD bool is_inf() const { return zz.is_zero(); }
+    ZK_HD bool is_inf() const { return zz.is_zero_raw(); }   // infinity is always ASSIGNED (zz = 0 limbs), never computed
     ZK_HD static XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
     ZK_HD static XYZZ from_affine(const Affine<F> &p) {
         if (p.is_inf()) return inf();

@@ -103,6 +103,7 @@ struct Fp {
         for (int i = 0; i < 8; i++) o |= v[i];
         return o == 0;
     }
+    ZK_HD bool is_zero_raw() const { return is_zero(); }   // canonical representation: same test
     ZK_HD bool operator==(const Fp &b) const {
         u32 o = 0;
 #pragma unroll

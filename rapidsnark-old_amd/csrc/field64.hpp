@@ -28,6 +28,7 @@ struct Fp64 {
     static Fp64 one() { Fp64 r; memcpy(r.v, PR::R1, 32); return r; }
     static Fp64 r2() { Fp64 r; memcpy(r.v, PR::R2, 32); return r; }
     bool is_zero() const { return (v[0] | v[1] | v[2] | v[3]) == 0; }
+    bool is_zero_raw() const { return is_zero(); }
     bool operator==(const Fp64 &o) const { return memcmp(v, o.v, 32) == 0; }
     bool operator!=(const Fp64 &o) const { return !(*this == o); }
 

@@ -55,7 +55,9 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits);
 // counts[W*nbuckets] += histogram of the signed digits of scalars[0..n)
 void launch_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
 // offsets[0..W*nbuckets] = exclusive scan(counts); offsets[W*nbuckets] = total; cursor = copy of offsets
+// `offsets` must hold total_buckets + 1 + msm_scan_extra_words(total_buckets) words (block sums live past the end)
 void launch_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total_buckets, hipStream_t s);
+uint32_t msm_scan_extra_words(uint32_t total_buckets);
 // entries[cursor[bucket]++] = idx | sign<<31
 void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
 // buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min.
@@ -72,6 +74,10 @@ void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_
 void launch_msm_reduce_g1(G1XYZZ *window_sums, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 void launch_msm_reduce_g2(G2XYZZ *window_sums, G2XYZZ *scratch, const G2XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p);
+
+// MSM tables live in HBM as canonical words of x*2^261 (the 29-bit-limb kernels' Montgomery radix);
+// converts n coordinates in place from the zkey's x*2^256.
+void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- synth.hip
 void launch_chain_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &P0, const G1Affine &Q, uint64_t n, hipStream_t s);

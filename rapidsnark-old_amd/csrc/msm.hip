@@ -17,6 +17,7 @@
 // Signed digits halve the bucket count; scalars are reduced mod r first so any 256-bit
 // input is accepted like the reference's raw-byte interface.
 #include "kernels.hpp"
+#include "field29.hpp"
 
 namespace zk {
 
@@ -60,24 +61,76 @@ __device__ __forceinline__ void store_el(Fq2 *p, const Fq2 &r) {
     store_el(&p->a, r.a);
     store_el(&p->b, r.b);
 }
+
+// Register representation of the MSM kernels: 9x29-bit signed limbs (field29.hpp).  HBM keeps
+// canonical 256-bit words of the SAME (2^261) Montgomery form; Reg<> converts at load/store.
+typedef Fp2T<Fq29> Fq2r;
+template <class FM> struct Reg;
+template <> struct Reg<Fq> {
+    typedef Fq29 type;
+    __device__ __forceinline__ static Fq29 load(const Fq *p) { return Fq29::load(load_el(p)); }
+    __device__ __forceinline__ static void store(Fq *p, const Fq29 &r) { store_el(p, Fq29::store(r)); }
+    __device__ __forceinline__ static void store256(Fq *p, const Fq29 &r) { store_el(p, Fq29::to_mont256(r)); }
+};
+template <> struct Reg<Fq2> {
+    typedef Fq2r type;
+    __device__ __forceinline__ static Fq2r load(const Fq2 *p) { return Fq2r{Reg<Fq>::load(&p->a), Reg<Fq>::load(&p->b)}; }
+    __device__ __forceinline__ static void store(Fq2 *p, const Fq2r &r) { Reg<Fq>::store(&p->a, r.a); Reg<Fq>::store(&p->b, r.b); }
+    __device__ __forceinline__ static void store256(Fq2 *p, const Fq2r &r) { Reg<Fq>::store256(&p->a, r.a); Reg<Fq>::store256(&p->b, r.b); }
+};
+#define REGF typename Reg<F>::type
+
 template <class F>
-__device__ __forceinline__ Affine<F> load_affine(const Affine<F> *p) {
-    return Affine<F>{load_el(&p->x), load_el(&p->y)};
+__device__ __forceinline__ Affine<REGF> load_affine(const Affine<F> *p) {
+    return Affine<REGF>{Reg<F>::load(&p->x), Reg<F>::load(&p->y)};
 }
 template <class F>
-__device__ __forceinline__ XYZZ<F> load_xyzz(const XYZZ<F> *p) {
-    return XYZZ<F>{load_el(&p->x), load_el(&p->y), load_el(&p->zz), load_el(&p->zzz)};
+__device__ __forceinline__ XYZZ<REGF> load_xyzz(const XYZZ<F> *p) {
+    return XYZZ<REGF>{Reg<F>::load(&p->x), Reg<F>::load(&p->y), Reg<F>::load(&p->zz), Reg<F>::load(&p->zzz)};
 }
 template <class F>
-__device__ __forceinline__ void store_xyzz(XYZZ<F> *p, const XYZZ<F> &v) {
-    store_el(&p->x, v.x);
-    store_el(&p->y, v.y);
-    store_el(&p->zz, v.zz);
-    store_el(&p->zzz, v.zzz);
+__device__ __forceinline__ void store_xyzz(XYZZ<F> *p, const XYZZ<REGF> &v) {
+    Reg<F>::store(&p->x, v.x);
+    Reg<F>::store(&p->y, v.y);
+    Reg<F>::store(&p->zz, v.zz);
+    Reg<F>::store(&p->zzz, v.zzz);
+}
+// final window sums leave the device in the zkey's own 2^256 Montgomery form
+template <class F>
+__device__ __forceinline__ void store_xyzz_mont256(XYZZ<F> *p, const XYZZ<REGF> &v) {
+    Reg<F>::store256(&p->x, v.x);
+    Reg<F>::store256(&p->y, v.y);
+    Reg<F>::store256(&p->zz, v.zz);
+    Reg<F>::store256(&p->zzz, v.zzz);
+}
+
+template <class F>
+__device__ __forceinline__ Affine<REGF> to_reg_affine(const Affine<F> &w);
+template <>
+__device__ __forceinline__ Affine<Fq29> to_reg_affine<Fq>(const Affine<Fq> &w) {
+    return Affine<Fq29>{Fq29::load(w.x), Fq29::load(w.y)};
+}
+template <>
+__device__ __forceinline__ Affine<Fq2r> to_reg_affine<Fq2>(const Affine<Fq2> &w) {
+    return Affine<Fq2r>{Fq2r{Fq29::load(w.x.a), Fq29::load(w.x.b)}, Fq2r{Fq29::load(w.y.a), Fq29::load(w.y.b)}};
+}
+
+// zkey tables arrive as x*2^256; convert every coordinate to x*2^261 in place (once, at create)
+__global__ __launch_bounds__(256) void k_fq_to_internal(Fq *coords, uint64_t n) {
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st)
+        store_el(coords + i, Fq29::store(Fq29::from_mont256(load_el(coords + i))));
+}
+void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
+    if (!n) return;
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
 }
 
 // Walk the signed c-bit digits of scalar s (standard form; reduced mod r here) and call
-// f(window, bucket_index = |d|-1, negative) for every non-zero digit d in [-2^(c-1), 2^(c-1)].
+// f(window, valid, bucket_index = |d|-1, negative) ONCE PER WINDOW, uniformly across the wave
+// (valid = digit != 0), for digits d in [-2^(c-1), 2^(c-1)].
 template <class Fn>
 __device__ __forceinline__ void for_each_digit(Fr s, uint32_t c, uint32_t W, Fn f) {
     // any 256-bit value is < 6r: bring it below r (never loops for well-formed inputs)
@@ -100,66 +153,158 @@ __device__ __forceinline__ void for_each_digit(Fr s, uint32_t c, uint32_t W, Fn 
             uint32_t d = ((uint32_t)buf & mask) + carry;
             buf >>= c;
             nb -= c;
-            if (d > half) {
-                carry = 1;
-                uint32_t nd = (1u << c) - d;          // |digit|; 0 when raw = 2^c-1 and carry = 1
-                if (nd) f(w, nd - 1u, true);
-            } else {
-                carry = 0;
-                if (d) f(w, d - 1u, false);
-            }
+            const bool neg = d > half;
+            carry = neg ? 1u : 0u;
+            uint32_t mag = neg ? (1u << c) - d : d;      // |digit|; 0 when raw = 2^c-1 and carry = 1
+            f(w, mag != 0, mag - 1u, neg);
             w++;
         }
     }
     // top window: whatever is left (value < 2^254 and W*c >= 255 => d <= 2^(c-1))
     uint32_t d = (uint32_t)buf + carry;
-    if (d) f(W - 1, d - 1u, false);
+    f(W - 1, d != 0, d - 1u, false);
+}
+
+// Wave-aggregated atomics.  Digit histograms are badly skewed exactly where it hurts: the top
+// window of uniform scalars has ~3-12 distinct digits, and real witnesses are mostly 0/1.
+// Up to AGG_PEEL times a leader's key is broadcast, the lanes holding the same key are
+// counted with one ballot, and ONE atomic is issued for the group; what is left (the
+// all-distinct case of ordinary windows) falls through to per-lane atomics.
+#define AGG_PEEL 4
+__device__ __forceinline__ void agg_count(uint32_t *counts, bool valid, uint32_t key) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll 1
+    for (int it = 0; it < AGG_PEEL; it++) {
+        uint64_t active = __ballot(valid);
+        if (!active) return;
+        int leader = __ffsll((unsigned long long)active) - 1;
+        uint32_t k0 = __shfl(key, leader);
+        bool mine = valid && key == k0;
+        uint64_t grp = __ballot(mine);
+        if (lane == (uint32_t)leader) atomicAdd(&counts[k0], (uint32_t)__popcll(grp));
+        if (mine) valid = false;
+    }
+    if (valid) atomicAdd(&counts[key], 1u);
+}
+__device__ __forceinline__ uint32_t agg_reserve(uint32_t *cursor, bool valid, uint32_t key) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t pos = 0;
+#pragma unroll 1
+    for (int it = 0; it < AGG_PEEL; it++) {
+        uint64_t active = __ballot(valid);
+        if (!active) return pos;
+        int leader = __ffsll((unsigned long long)active) - 1;
+        uint32_t k0 = __shfl(key, leader);
+        bool mine = valid && key == k0;
+        uint64_t grp = __ballot(mine);
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&cursor[k0], (uint32_t)__popcll(grp));
+        base = __shfl(base, leader);
+        if (mine) {
+            pos = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+            valid = false;
+        }
+    }
+    if (valid) pos = atomicAdd(&cursor[key], 1u);
+    return pos;
 }
 
 __global__ __launch_bounds__(256) void k_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
-        Fr s = load_el(scalars + i);
-        for_each_digit(s, p.c, p.W, [&](uint32_t w, uint32_t b, bool) { atomicAdd(&counts[w * p.nbuckets + b], 1u); });
+    // whole waves iterate together (ballots need the wave's lanes in lock step): pad the loop bound
+    uint64_t nround = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += st) {
+        const bool live = i < n;
+        Fr s = live ? load_el(scalars + i) : Fr::zero();
+        for_each_digit(s, p.c, p.W, [&](uint32_t w, bool valid, uint32_t b, bool) {
+            agg_count(counts, valid && live, w * p.nbuckets + b);
+        });
     }
 }
 
 __global__ __launch_bounds__(256) void k_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
-        Fr s = load_el(scalars + i);
-        for_each_digit(s, p.c, p.W, [&](uint32_t w, uint32_t b, bool neg) {
-            uint32_t pos = atomicAdd(&cursor[w * p.nbuckets + b], 1u);
-            entries[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+    uint64_t nround = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += st) {
+        const bool live = i < n;
+        Fr s = live ? load_el(scalars + i) : Fr::zero();
+        for_each_digit(s, p.c, p.W, [&](uint32_t w, bool valid, uint32_t b, bool neg) {
+            const bool v = valid && live;
+            uint32_t pos = agg_reserve(cursor, v, w * p.nbuckets + b);
+            if (v) entries[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
         });
     }
 }
 
-// single workgroup exclusive scan (total_buckets <= a few million): each of 1024 lanes owns a
-// contiguous slice; slice sums are scanned through LDS.
-__global__ __launch_bounds__(1024) void k_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total) {
-    __shared__ uint32_t sums[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t lo = tid * per;
-    const uint32_t hi = lo + per < total ? lo + per : total;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += counts[i];
-    sums[tid] = s;
+// Exclusive scan in three coalesced launches: per-block (4096 elements) local scan + block
+// sums, scan of the block sums (one block), add-back.  offsets[total] = grand total.
+#define SCAN_BLOCK 1024u
+#define SCAN_ELEMS 4096u
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &block_total) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) lds[wave] = x;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = tid >= d ? sums[tid - d] : 0;
+    if (wave == 0) {
+        uint32_t s = lane < (SCAN_BLOCK / 64) ? lds[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            uint32_t y = __shfl_up(s, d);
+            if (lane >= (uint32_t)d) s += y;
+        }
+        if (lane < (SCAN_BLOCK / 64)) lds[lane] = s;      // inclusive wave totals
+    }
+    __syncthreads();
+    uint32_t wave_off = wave ? lds[wave - 1] : 0;
+    block_total = lds[SCAN_BLOCK / 64 - 1];
+    return wave_off + x - v;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(uint32_t *offsets, uint32_t *block_sums, const uint32_t *counts, uint32_t total) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = base + j < total ? counts[base + j] : 0;
+    uint32_t sum = v[0] + v[1] + v[2] + v[3], bt;
+    uint32_t ex = block_exclusive_scan(sum, lds, bt);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (base + j < total) offsets[base + j] = ex;
+        ex += v[j];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = bt;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(uint32_t *block_sums, uint32_t nblocks, uint32_t *grand_total) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += SCAN_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? block_sums[i] : 0, bt;
+        uint32_t ex = block_exclusive_scan(v, lds, bt) + carry_s;
+        if (i < nblocks) block_sums[i] = ex;
         __syncthreads();
-        sums[tid] += v;
+        if (threadIdx.x == 0) carry_s += bt;
         __syncthreads();
     }
-    uint32_t run = sums[tid] - s;
-    for (uint32_t i = lo; i < hi; i++) {
-        offsets[i] = run;
-        cursor[i] = run;
-        run += counts[i];
-    }
-    if (tid == 1023) offsets[total] = sums[1023];
+    if (threadIdx.x == 0) *grand_total = carry_s;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, uint32_t *cursor, const uint32_t *block_sums, uint32_t total) {
+    const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+    const uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (base + j < total) {
+            uint32_t o = offsets[base + j] + add;
+            offsets[base + j] = o;
+            cursor[base + j] = o;
+        }
 }
 
 // ---------------------------------------------------------------- load-balanced accumulation
@@ -201,25 +346,31 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
         uint32_t b = bl;
         uint32_t bend = offsets[b + 1];
         bool started_before = offsets[b] < lo;
-        XYZZ<F> acc = XYZZ<F>::inf();
-        Affine<F> nextP = Affine<F>::inf();
-        bool nextNeg = false;
+        typedef REGF FR;
+        XYZZ<FR> acc = XYZZ<FR>::inf();
+        Affine<F> nextP;                 // raw words: the next point is in flight while this one is added
+        bool nextNeg = false, nextSkip = false;
         auto fetch = [&](uint32_t pos) {
             uint32_t ent = entries[pos];
             uint32_t idx = ent & 0x7fffffffu;
             nextNeg = (ent >> 31) != 0;
-            if (idx >= idx_min) nextP = load_affine(points + (idx - idx_sub));
-            else nextP = Affine<F>::inf();
+            nextSkip = idx < idx_min;
+            const Affine<F> *src = points + (nextSkip ? 0 : idx - idx_sub);
+            nextP.x = load_el(&src->x);
+            nextP.y = load_el(&src->y);
         };
         uint32_t e = lo;
         fetch(e);
         while (e < hi) {
-            Affine<F> P = nextP;
-            bool ng = nextNeg;
+            Affine<F> Pw = nextP;
+            bool ng = nextNeg, skip = nextSkip;
             e++;
             if (e < hi) fetch(e);
-            if (ng) P.y = F::neg(P.y);
-            madd(acc, P);
+            if (!skip) {
+                Affine<FR> P = to_reg_affine<F>(Pw);
+                if (ng) P.y = FR::neg(P.y);
+                madd(acc, P);
+            }
             if (e == bend || e == hi) {              // the run of bucket b ends here (or is cut)
                 const bool ends = (e == bend);
                 if (!started_before && ends) {
@@ -236,7 +387,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
                 if (e < hi) {                        // next non-empty bucket
                     do { b++; bend = offsets[b + 1]; } while (bend == e);
                     started_before = false;
-                    acc = XYZZ<F>::inf();
+                    acc = XYZZ<FR>::inf();
                 }
             }
         }
@@ -257,8 +408,9 @@ __global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XY
     const uint32_t lo = t * ACC_CHUNK_N;
     const uint32_t hi = lo + ACC_CHUNK_N < nitems ? lo + ACC_CHUNK_N : nitems;
     uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
+    typedef REGF FR;
     uint32_t cur = SLOT_EMPTY, cflag = 0;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ<FR> acc = XYZZ<FR>::inf();
     auto flush = [&]() {
         if (cur == SLOT_EMPTY) return;
         if ((cflag & FLAG_STARTS) && (cflag & FLAG_ENDS)) {
@@ -281,7 +433,7 @@ __global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XY
             flush();
             cur = k;
             cflag = fl & FLAG_STARTS;
-            acc = XYZZ<F>::inf();
+            acc = XYZZ<FR>::inf();
         }
         cflag = (cflag & FLAG_STARTS) | (fl & FLAG_ENDS);
         add(acc, load_xyzz(in_part + i));
@@ -303,7 +455,8 @@ __global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, con
     const uint32_t chunks_per_window = nbuckets / chunk;
     const uint32_t cw = t % chunks_per_window;          // chunk index inside its window
     const XYZZ<F> *B = buckets + (uint64_t)t * chunk;   // windows (and MSMs) are laid back to back
-    XYZZ<F> run = XYZZ<F>::inf(), sum = XYZZ<F>::inf();
+    typedef REGF FR;
+    XYZZ<FR> run = XYZZ<FR>::inf(), sum = XYZZ<FR>::inf();
     for (int j = (int)chunk - 1; j >= 0; j--) {
         add(run, load_xyzz(B + j));
         add(sum, run);
@@ -311,7 +464,7 @@ __global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, con
     // sum += (cw*chunk) * run   — double-and-add, MSB first
     uint32_t k = cw * chunk;
     if (k) {
-        XYZZ<F> m = XYZZ<F>::inf();
+        XYZZ<FR> m = XYZZ<FR>::inf();
         for (int bit = 31 - __clz(k); bit >= 0; bit--) {
             m = dbl(m);
             if ((k >> bit) & 1u) add(m, run);
@@ -326,21 +479,22 @@ template <class F>
 __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_final(XYZZ<F> *window_sums, const XYZZ<F> *scratch,
                                                                      uint32_t chunks_per_window) {
     extern __shared__ uint32_t lds_raw[];
-    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(lds_raw);
+    typedef REGF FR;
+    XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);
     const XYZZ<F> *X = scratch + (uint64_t)blockIdx.x * chunks_per_window;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ<FR> acc = XYZZ<FR>::inf();
     for (uint32_t i = threadIdx.x; i < chunks_per_window; i += REDUCE_THREADS) add(acc, load_xyzz(X + i));
     lds[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = REDUCE_THREADS / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
-            XYZZ<F> o = lds[threadIdx.x + s];
+            XYZZ<FR> o = lds[threadIdx.x + s];
             add(acc, o);
             lds[threadIdx.x] = acc;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_xyzz(window_sums + blockIdx.x, acc);
+    if (threadIdx.x == 0) store_xyzz_mont256(window_sums + blockIdx.x, acc);    // back to the zkey's 2^256 form
 }
 
 static inline uint32_t reduce_chunk_for(MsmPlan p) { return p.nbuckets < REDUCE_CHUNK ? p.nbuckets : REDUCE_CHUNK; }
@@ -356,8 +510,16 @@ void launch_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p
     hipLaunchKernelGGL(k_msm_count, dim3((uint32_t)g), dim3(256), 0, s, counts, scalars, n, p);
 }
 void launch_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, s, offsets, cursor, counts, total);
+    // block sums live in `cursor` (overwritten by the add-back afterwards is fine: k_scan_add
+    // reads block_sums[blockIdx.x] before any cursor element of a LATER block is written, but to
+    // stay race-free the sums are kept past the end of the scanned range instead)
+    uint32_t nblocks = (total + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    uint32_t *block_sums = offsets + total + 1;       // offsets is allocated total + 1 + nblocks
+    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, offsets, block_sums, counts, total);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums, nblocks, offsets + total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, offsets, cursor, (const uint32_t *)block_sums, total);
 }
+uint32_t msm_scan_extra_words(uint32_t total) { return (total + SCAN_ELEMS - 1) / SCAN_ELEMS; }
 void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
     if (!n) return;
     uint64_t g = (n + 255) / 256;
@@ -416,7 +578,7 @@ static void launch_reduce(XYZZ<F> *window_sums, XYZZ<F> *scratch, const XYZZ<F> 
     uint32_t cpw = p.nbuckets / chunk;
     uint32_t total_chunks = n_msm * p.W * cpw;
     hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks + 127) / 128), dim3(128), 0, s, scratch, buckets, p.nbuckets, chunk, total_chunks);
-    hipLaunchKernelGGL(k_msm_reduce_final<F>, dim3(n_msm * p.W), dim3(REDUCE_THREADS), REDUCE_THREADS * sizeof(XYZZ<F>), s, window_sums, scratch, cpw);
+    hipLaunchKernelGGL(k_msm_reduce_final<F>, dim3(n_msm * p.W), dim3(REDUCE_THREADS), REDUCE_THREADS * sizeof(XYZZ<typename Reg<F>::type>), s, window_sums, scratch, cpw);
 }
 void launch_msm_reduce_g1(G1XYZZ *ws, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     launch_reduce<Fq>(ws, scratch, buckets, n_msm, p, s);

@@ -80,7 +80,7 @@ struct SortBufs {
         n = n_;
         plan = make_msm_plan(n ? n : 1, window_bits);
         counts.alloc(total_buckets());
-        offsets.alloc(total_buckets() + 1);
+        offsets.alloc(total_buckets() + 1 + msm_scan_extra_words(total_buckets()));
         cursor.alloc(total_buckets());
         entries.alloc((size_t)(n ? n : 1) * plan.W);
     }
@@ -276,7 +276,13 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         uint64_t cnt = hi - lo;
         p->ptsC.alloc(cnt ? cnt : 1);
         p->ptsC.upload((const uint8_t *)z->pointsC + (lo - first) * 64, cnt, s);
+        launch_fq_to_internal((Fq *)p->ptsC.p, cnt * 2, s);
     }
+    // MSM kernels work in the 2^261 Montgomery form (field29.hpp): convert the tables once
+    launch_fq_to_internal((Fq *)p->ptsA.p, nv * 2, s);
+    launch_fq_to_internal((Fq *)p->ptsB1.p, nv * 2, s);
+    launch_fq_to_internal((Fq *)p->ptsB2.p, nv * 4, s);
+    launch_fq_to_internal((Fq *)p->ptsH.p, nh * 2, s);
 
     // --- workspace
     p->wtns.alloc(nV);
@@ -571,6 +577,7 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     pts.alloc(n);
     sc.alloc(n);
     pts.upload(bases, n, 0);
+    launch_fq_to_internal((Fq *)pts.p, n * (sizeof(AffT) / 32), 0);
     sc.upload(scalars, n, 0);
     SortBufs sb;
     sb.alloc(n, 0);

@@ -1,0 +1,123 @@
+// Validates field29.hpp (9x29-bit signed limbs) against the proven 8x32 Montgomery code and
+// times both.  tools/, not product code.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include <random>
+#include "../rapidsnark-old_amd/csrc/field29.hpp"
+using namespace zk;
+
+__global__ void k_check(const Fq *a, const Fq *b, int n, unsigned *bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq x = a[i], y = b[i];
+    Fq29 X = Fq29::from_mont256(x), Y = Fq29::from_mont256(y);
+    unsigned f = 0;
+    // 1. product
+    if (!(Fq29::to_mont256(Fq29::mul(X, Y)) == Fq::mul(x, y))) f |= 1;
+    // 2. add / sub / dbl / neg
+    if (!(Fq29::to_mont256(Fq29::add(X, Y)) == Fq::add(x, y))) f |= 2;
+    if (!(Fq29::to_mont256(Fq29::sub(X, Y)) == Fq::sub(x, y))) f |= 4;
+    if (!(Fq29::to_mont256(Fq29::dbl(X)) == Fq::dbl(x))) f |= 8;
+    if (!(Fq29::to_mont256(Fq29::neg(X)) == Fq::neg(x))) f |= 16;
+    // 3. a chain mixing everything (same sequence in both representations)
+    Fq t = x;
+    Fq29 T = X;
+    for (int k = 0; k < 12; k++) {
+        Fq u = Fq::sub(Fq::mul(t, y), Fq::add(x, Fq::dbl(t)));
+        Fq29 U = Fq29::sub(Fq29::mul(T, Y), Fq29::add(X, Fq29::dbl(T)));
+        Fq v = Fq::sub(Fq::sub(Fq::sqr(u), Fq::dbl(Fq::dbl(t))), Fq::neg(y));
+        Fq29 V = Fq29::sub(Fq29::sub(Fq29::sqr(U), Fq29::dbl(Fq29::dbl(T))), Fq29::neg(Y));
+        t = Fq::mul(v, Fq::sub(u, v));
+        T = Fq29::mul(V, Fq29::sub(U, V));
+    }
+    if (!(Fq29::to_mont256(T) == t)) f |= 32;
+    // 4. exact zero tests
+    if (!Fq29::sub(X, X).is_zero()) f |= 64;
+    if (!Fq29::add(X, Fq29::neg(X)).is_zero()) f |= 64;
+    if (!Fq29::sub(Fq29::mul(X, Y), Fq29::mul(Y, X)).is_zero()) f |= 128;
+    Fq29 W = Fq29::sub(Fq29::add(Fq29::dbl(Fq29::dbl(X)), Y), Fq29::add(Fq29::dbl(X), Fq29::add(Fq29::dbl(X), Y)));
+    if (!W.is_zero()) f |= 256;
+    if (!(x == y) && Fq29::sub(X, Y).is_zero()) f |= 512;
+    if (!x.is_zero() && X.is_zero()) f |= 512;
+    // 5. load/store round trip of a canonical value
+    if (!(Fq29::store(Fq29::load(x)) == x)) f |= 1024;
+    if (f) atomicOr(bad, f);
+}
+
+template <int NCH>
+__global__ void k_mul32(unsigned *out, const Fq *a, int iters) {
+    Fq y = a[threadIdx.x & 255], x[NCH];
+    for (int c = 0; c < NCH; c++) { x[c] = y; x[c].v[0] ^= c; }
+    for (int i = 0; i < iters; i++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) x[c] = Fq::mul(x[c], y);
+    unsigned o = 0;
+    for (int c = 0; c < NCH; c++) for (int k = 0; k < 8; k++) o ^= x[c].v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = o;
+}
+template <int NCH>
+__global__ void k_mul29(unsigned *out, const Fq *a, int iters) {
+    Fq29 y = Fq29::load(a[threadIdx.x & 255]), x[NCH];
+    for (int c = 0; c < NCH; c++) { x[c] = y; x[c].l[0] ^= c; }
+    for (int i = 0; i < iters; i++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) x[c] = Fq29::mul(x[c], y);
+    unsigned o = 0;
+    for (int c = 0; c < NCH; c++) for (int k = 0; k < 9; k++) o ^= (unsigned)x[c].l[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = o;
+}
+__global__ void k_addsub29(unsigned *out, const Fq *a, int iters) {
+    Fq29 y = Fq29::load(a[threadIdx.x & 255]), x = y;
+    x.l[0] ^= 1;
+    for (int i = 0; i < iters; i++) { x = Fq29::add(x, y); y = Fq29::sub(y, x); }
+    unsigned o = 0;
+    for (int k = 0; k < 9; k++) o ^= (unsigned)(x.l[k] ^ y.l[k]);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = o;
+}
+
+template <class K, class... A>
+static double timeit(K k, int blocks, int threads, A... args) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, args...); hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 3; r++) {
+        hipEventRecord(e0, 0); hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, args...); hipEventRecord(e1, 0);
+        hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    return best * 1e-3;
+}
+
+int main() {
+    const int n = 1 << 16;
+    std::mt19937_64 rng(7);
+    const uint64_t q[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    std::vector<uint64_t> ha(n * 4), hb(n * 4);
+    auto gen = [&](uint64_t *o) { for (;;) { for (int k = 0; k < 4; k++) o[k] = rng(); o[3] &= 0x3fffffffffffffffull; if (o[3] < q[3]) return; } };
+    for (int i = 0; i < n; i++) { gen(&ha[i * 4]); gen(&hb[i * 4]); }
+    // edge cases
+    for (int k = 0; k < 4; k++) { ha[k] = 0; hb[k] = 0; ha[4 + k] = 0; ha[8 + k] = q[k]; hb[8 + k] = q[k]; ha[12 + k] = q[k]; }
+    ha[4] = 1; ha[8] -= 1; hb[8] -= 1; ha[12] -= 1; hb[12] = 1; hb[13] = hb[14] = hb[15] = 0;
+    for (int k = 0; k < 4; k++) hb[16 + k] = ha[16 + k];      // equal operands
+    Fq *da, *db; unsigned *dbad, *dout;
+    hipMalloc(&da, n * 32); hipMalloc(&db, n * 32); hipMalloc(&dbad, 4);
+    hipMemcpy(da, ha.data(), n * 32, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), n * 32, hipMemcpyHostToDevice);
+    hipMemset(dbad, 0, 4);
+    hipLaunchKernelGGL(k_check, dim3(n / 256), dim3(256), 0, 0, da, db, n, dbad);
+    unsigned bad; hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost);
+    printf("fq29 check flags = 0x%x  (%s)\n", bad, bad ? "FAIL" : "all identities hold on 65536 random + edge inputs");
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    int cus = prop.multiProcessorCount;
+    hipMalloc(&dout, (size_t)cus * 8 * 256 * 4);
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        int b = cus * wps, iters = 2000;
+        double t32 = timeit(k_mul32<1>, b, 256, dout, da, iters);
+        double t29 = timeit(k_mul29<1>, b, 256, dout, da, iters);
+        double t29_4 = timeit(k_mul29<4>, b, 256, dout, da, iters);
+        double nm = (double)b * 256 * iters;
+        printf("waves/SIMD=%d: 8x32 %.1f Gmul/s | 9x29 %.1f Gmul/s (x%.2f) | 9x29 4-chain %.1f Gmul/s\n", wps, nm / t32 * 1e-9, nm / t29 * 1e-9, t32 / t29, 4 * nm / t29_4 * 1e-9);
+    }
+    double ta = timeit(k_addsub29, cus * 8, 256, dout, da, 4000);
+    printf("9x29 add/sub: %.1f Gop/s\n", (double)cus * 8 * 256 * 4000 * 2 / ta * 1e-9);
+    return 0;
+}
