@@ -52,14 +52,16 @@ struct MsmPlan {
 };
 MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits);
 
-// counts[W*nbuckets] += histogram of the signed digits of scalars[0..n)
-void launch_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
-// offsets[0..W*nbuckets] = exclusive scan(counts); offsets[W*nbuckets] = total; cursor = copy of offsets
-// `offsets` must hold total_buckets + 1 + msm_scan_extra_words(total_buckets) words (block sums live past the end)
-void launch_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total_buckets, hipStream_t s);
-uint32_t msm_scan_extra_words(uint32_t total_buckets);
-// entries[cursor[bucket]++] = idx | sign<<31
-void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
+// Digit recoding + counting sort of a scalar vector into bucket order (shared by every MSM over
+// that vector).  Buffer sizes (in elements) come from msm_sort_sizes().
+struct MsmSortSizes {
+    uint64_t digits_u16, counts_u32, starts_u32, offsets_u32, entries_u32;
+};
+MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p);
+uint32_t msm_scan_extra_words(uint32_t total);
+// offsets[0..W*nbuckets] = start of every bucket's run in entries[]; entries = idx | sign<<31
+void launch_msm_sort(uint32_t *offsets, uint32_t *entries, uint16_t *digits, uint32_t *counts, uint32_t *starts,
+                     const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
 // buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min.
 // max_entries: upper bound of offsets[total_buckets] (= n*W); ws_*: msm_accum_workspace_slots() slots.
 uint64_t msm_accum_workspace_slots(uint64_t max_entries);

@@ -2,9 +2,9 @@
 // ParallelMultiexp behind Curve::multiMulByScalar (call sites src/groth16.cpp:173,183,190,197,204).
 //
 // MI355X design (ffiasm keeps nThreads x 2^c per-thread bucket arrays; that makes no sense here):
-//   1. k_msm_count   : signed c-bit digits of every scalar -> histogram per (window, bucket)
-//   2. k_msm_scan    : exclusive scan -> bucket offsets
-//   3. k_msm_scatter : counting sort of (point index | sign) into bucket order
+//   1. k_msm_digits       : signed c-bit digits of every scalar, window-major 16-bit codes
+//   2. k_msm_count_lds    : per-(window, slice) histograms entirely in LDS; k_scan_* : exclusive scan
+//   3. k_msm_scatter_lds  : counting sort of (point index | sign) into bucket order, LDS-ranked
 //      (1-3 run ONCE per scalar vector: the witness sort is shared by MSM A, B1, B2, C,
 //       which the reference recomputes four times, src/groth16.cpp:183-204)
 //   4. k_msm_accum_l1/_ln : load-balanced segmented accumulation — every lane mixed-adds a
@@ -36,7 +36,9 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits) {
     if (c < 2) c = 2;
     if (c > 20) c = 20;
     p.c = c;
-    p.W = (255 + c - 1) / c;
+    if (c > 16) c = 16;             // the LDS histogram sort holds 2^(c-1) counters per workgroup
+    p.c = c;
+    p.W = (256 + c - 1) / c;        // W*c >= 256: the top digit is never negative (symmetric recoding)
     p.nbuckets = 1u << (c - 1);
     return p;
 }
@@ -128,112 +130,100 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
 }
 
-// Walk the signed c-bit digits of scalar s (standard form; reduced mod r here) and call
-// f(window, valid, bucket_index = |d|-1, negative) ONCE PER WINDOW, uniformly across the wave
-// (valid = digit != 0), for digits d in [-2^(c-1), 2^(c-1)].
-template <class Fn>
-__device__ __forceinline__ void for_each_digit(Fr s, uint32_t c, uint32_t W, Fn f) {
-    // any 256-bit value is < 6r: bring it below r (never loops for well-formed inputs)
-    for (int k = 0; k < 6; k++) {
-        Fr d;
-        u32 bw = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) d.v[i] = subb(s.v[i], FrParams::P[i], bw);
-        if (bw) break;
-        s = d;
-    }
+// ---------------------------------------------------------------- digits + LDS counting sort
+// Signed c-bit digits d in [-2^(c-1), 2^(c-1) - 1] (a window value >= 2^(c-1) becomes negative
+// and carries into the next window).  Digits are stored window-major as 16-bit codes:
+// bit 15 = sign, bits 0..14 = |d| - 1, 0x7FFF = zero digit (+2^(c-1) never occurs, so that
+// code is free even at c = 16).
+//
+// MI355X-specific: a whole window's histogram (2^(c-1) <= 32768 counters = 128 KiB) fits in
+// one CU's 160 KiB LDS.  Workgroup (window w, slice s) histograms its slice of the scalars with
+// LDS atomics only and writes counts[w][bucket][s]; one exclusive scan turns that into the
+// start of every (bucket, slice) run; the scatter workgroups rank their entries with LDS
+// atomics again.  No global atomics at all (the first version spent 83 % of its cycles
+// waiting on them), and the entry order inside a bucket is deterministic.
+#define DIGIT_ZERO 0x7FFFu
+#define SORT_SLICES 16u
+#define SORT_THREADS 1024u
+
+__global__ __launch_bounds__(256) void k_msm_digits(uint16_t *digits, const Fr *scalars, uint64_t n, MsmPlan p) {
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t c = p.c, W = p.W;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    uint64_t buf = 0;
-    uint32_t nb = 0, w = 0, carry = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        Fr s = load_el(scalars + i);
+        // any 256-bit value is < 6r: bring it below r (never loops for well-formed inputs)
+        for (int k = 0; k < 6; k++) {
+            Fr d;
+            u32 bw = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        buf |= (uint64_t)s.v[k] << nb;
-        nb += 32;
-        while (nb >= c && w + 1 < W) {
-            uint32_t d = ((uint32_t)buf & mask) + carry;
-            buf >>= c;
-            nb -= c;
-            const bool neg = d > half;
+            for (int j = 0; j < 8; j++) d.v[j] = subb(s.v[j], FrParams::P[j], bw);
+            if (bw) break;
+            s = d;
+        }
+        uint64_t buf = 0;
+        uint32_t nb = 0, w = 0, carry = 0;
+        auto emit = [&](uint32_t raw) {
+            uint32_t d = raw + carry;
+            const bool neg = d >= half;                  // digits in [-2^(c-1), 2^(c-1) - 1]
             carry = neg ? 1u : 0u;
-            uint32_t mag = neg ? (1u << c) - d : d;      // |digit|; 0 when raw = 2^c-1 and carry = 1
-            f(w, mag != 0, mag - 1u, neg);
+            uint32_t mag = neg ? (1u << c) - d : d;      // 0 when raw = 2^c - 1 and carry = 1
+            uint32_t code = mag ? ((mag - 1u) | (neg ? 0x8000u : 0u)) : DIGIT_ZERO;
+            digits[(uint64_t)w * n + i] = (uint16_t)code;
             w++;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            buf |= (uint64_t)s.v[k] << nb;
+            nb += 32;
+            while (nb >= c && w + 1 < W) {
+                emit((uint32_t)buf & mask);
+                buf >>= c;
+                nb -= c;
+            }
+        }
+        emit((uint32_t)buf & mask);   // top window: value < 2^254 and W*c >= 256 => never negative
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_count_lds(uint32_t *counts, const uint16_t *digits, uint64_t n, MsmPlan p) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t w = blockIdx.x, slice = blockIdx.y, nb = p.nbuckets;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint64_t lo = n * slice / SORT_SLICES, hi = n * (slice + 1) / SORT_SLICES;
+    const uint16_t *d = digits + (uint64_t)w * n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        uint32_t code = d[i];
+        if (code != DIGIT_ZERO) atomicAdd(&hist[code & 0x7FFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = counts + (uint64_t)w * nb * SORT_SLICES + slice;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) out[(uint64_t)b * SORT_SLICES] = hist[b];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_lds(uint32_t *entries, const uint32_t *starts, const uint16_t *digits,
+                                                                   uint64_t n, MsmPlan p) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t w = blockIdx.x, slice = blockIdx.y, nb = p.nbuckets;
+    const uint32_t *in = starts + (uint64_t)w * nb * SORT_SLICES + slice;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cursor[b] = in[(uint64_t)b * SORT_SLICES];
+    __syncthreads();
+    const uint64_t lo = n * slice / SORT_SLICES, hi = n * (slice + 1) / SORT_SLICES;
+    const uint16_t *d = digits + (uint64_t)w * n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        uint32_t code = d[i];
+        if (code != DIGIT_ZERO) {
+            uint32_t pos = atomicAdd(&cursor[code & 0x7FFFu], 1u);
+            entries[pos] = (uint32_t)i | ((code & 0x8000u) << 16);
         }
     }
-    // top window: whatever is left (value < 2^254 and W*c >= 255 => d <= 2^(c-1))
-    uint32_t d = (uint32_t)buf + carry;
-    f(W - 1, d != 0, d - 1u, false);
 }
 
-// Wave-aggregated atomics.  Digit histograms are badly skewed exactly where it hurts: the top
-// window of uniform scalars has ~3-12 distinct digits, and real witnesses are mostly 0/1.
-// Up to AGG_PEEL times a leader's key is broadcast, the lanes holding the same key are
-// counted with one ballot, and ONE atomic is issued for the group; what is left (the
-// all-distinct case of ordinary windows) falls through to per-lane atomics.
-#define AGG_PEEL 4
-__device__ __forceinline__ void agg_count(uint32_t *counts, bool valid, uint32_t key) {
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll 1
-    for (int it = 0; it < AGG_PEEL; it++) {
-        uint64_t active = __ballot(valid);
-        if (!active) return;
-        int leader = __ffsll((unsigned long long)active) - 1;
-        uint32_t k0 = __shfl(key, leader);
-        bool mine = valid && key == k0;
-        uint64_t grp = __ballot(mine);
-        if (lane == (uint32_t)leader) atomicAdd(&counts[k0], (uint32_t)__popcll(grp));
-        if (mine) valid = false;
-    }
-    if (valid) atomicAdd(&counts[key], 1u);
-}
-__device__ __forceinline__ uint32_t agg_reserve(uint32_t *cursor, bool valid, uint32_t key) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t pos = 0;
-#pragma unroll 1
-    for (int it = 0; it < AGG_PEEL; it++) {
-        uint64_t active = __ballot(valid);
-        if (!active) return pos;
-        int leader = __ffsll((unsigned long long)active) - 1;
-        uint32_t k0 = __shfl(key, leader);
-        bool mine = valid && key == k0;
-        uint64_t grp = __ballot(mine);
-        uint32_t base = 0;
-        if (lane == (uint32_t)leader) base = atomicAdd(&cursor[k0], (uint32_t)__popcll(grp));
-        base = __shfl(base, leader);
-        if (mine) {
-            pos = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
-            valid = false;
-        }
-    }
-    if (valid) pos = atomicAdd(&cursor[key], 1u);
-    return pos;
-}
-
-__global__ __launch_bounds__(256) void k_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p) {
-    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
-    // whole waves iterate together (ballots need the wave's lanes in lock step): pad the loop bound
-    uint64_t nround = (n + 63) & ~63ull;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += st) {
-        const bool live = i < n;
-        Fr s = live ? load_el(scalars + i) : Fr::zero();
-        for_each_digit(s, p.c, p.W, [&](uint32_t w, bool valid, uint32_t b, bool) {
-            agg_count(counts, valid && live, w * p.nbuckets + b);
-        });
-    }
-}
-
-__global__ __launch_bounds__(256) void k_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p) {
-    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t nround = (n + 63) & ~63ull;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += st) {
-        const bool live = i < n;
-        Fr s = live ? load_el(scalars + i) : Fr::zero();
-        for_each_digit(s, p.c, p.W, [&](uint32_t w, bool valid, uint32_t b, bool neg) {
-            const bool v = valid && live;
-            uint32_t pos = agg_reserve(cursor, v, w * p.nbuckets + b);
-            if (v) entries[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
-        });
-    }
+// offsets[k] = start of bucket k = starts[k * SORT_SLICES]; offsets[total] = grand total
+__global__ __launch_bounds__(256) void k_msm_compact_offsets(uint32_t *offsets, const uint32_t *starts, uint32_t total) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= total) offsets[k] = starts[(uint64_t)k * SORT_SLICES];
 }
 
 // Exclusive scan in three coalesced launches: per-block (4096 elements) local scan + block
@@ -295,16 +285,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(uint32_t *block_sums, 
     }
     if (threadIdx.x == 0) *grand_total = carry_s;
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, uint32_t *cursor, const uint32_t *block_sums, uint32_t total) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, const uint32_t *block_sums, uint32_t total) {
     const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
     const uint32_t add = block_sums[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        if (base + j < total) {
-            uint32_t o = offsets[base + j] + add;
-            offsets[base + j] = o;
-            cursor[base + j] = o;
-        }
+        if (base + j < total) offsets[base + j] += add;
 }
 
 // ---------------------------------------------------------------- load-balanced accumulation
@@ -503,29 +489,51 @@ uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
     return (uint64_t)n_msm * p.W * (p.nbuckets / reduce_chunk_for(p));
 }
 
-void launch_msm_count(uint32_t *counts, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
-    if (!n) return;
-    uint64_t g = (n + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_msm_count, dim3((uint32_t)g), dim3(256), 0, s, counts, scalars, n, p);
-}
-void launch_msm_scan(uint32_t *offsets, uint32_t *cursor, const uint32_t *counts, uint32_t total, hipStream_t s) {
-    // block sums live in `cursor` (overwritten by the add-back afterwards is fine: k_scan_add
-    // reads block_sums[blockIdx.x] before any cursor element of a LATER block is written, but to
-    // stay race-free the sums are kept past the end of the scanned range instead)
+// exclusive scan of counts[0..total) -> out[0..total], out[total] = grand total;
+// out must hold total + 1 + msm_scan_extra_words(total) words (block sums live past the end)
+static void launch_scan(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s) {
     uint32_t nblocks = (total + SCAN_ELEMS - 1) / SCAN_ELEMS;
-    uint32_t *block_sums = offsets + total + 1;       // offsets is allocated total + 1 + nblocks
-    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, offsets, block_sums, counts, total);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums, nblocks, offsets + total);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, offsets, cursor, (const uint32_t *)block_sums, total);
+    uint32_t *block_sums = out + total + 1;
+    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, block_sums, counts, total);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums, nblocks, out + total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, (const uint32_t *)block_sums, total);
 }
 uint32_t msm_scan_extra_words(uint32_t total) { return (total + SCAN_ELEMS - 1) / SCAN_ELEMS; }
-void launch_msm_scatter(uint32_t *entries, uint32_t *cursor, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
-    if (!n) return;
-    uint64_t g = (n + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_msm_scatter, dim3((uint32_t)g), dim3(256), 0, s, entries, cursor, scalars, n, p);
+
+MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p) {
+    MsmSortSizes z;
+    uint64_t tb = (uint64_t)p.W * p.nbuckets;
+    z.digits_u16 = (n ? n : 1) * p.W;
+    z.counts_u32 = tb * SORT_SLICES;
+    z.starts_u32 = tb * SORT_SLICES + 1 + msm_scan_extra_words((uint32_t)(tb * SORT_SLICES));
+    z.offsets_u32 = tb + 1;
+    z.entries_u32 = (n ? n : 1) * p.W;
+    return z;
 }
+
+// digits -> LDS histograms -> scan -> LDS-ranked scatter -> compact bucket offsets
+void launch_msm_sort(uint32_t *offsets, uint32_t *entries, uint16_t *digits, uint32_t *counts, uint32_t *starts,
+                     const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
+    const uint32_t tb = p.W * p.nbuckets;
+    const size_t lds = (size_t)p.nbuckets * 4;
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
+        (void)hipFuncSetAttribute((const void *)k_msm_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (n) {
+        uint64_t g = (n + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(k_msm_digits, dim3((uint32_t)g), dim3(256), 0, s, digits, scalars, n, p);
+    }
+    hipLaunchKernelGGL(k_msm_count_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, counts, (const uint16_t *)digits, n, p);
+    launch_scan(starts, counts, tb * SORT_SLICES, s);
+    hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, entries, (const uint32_t *)starts,
+                       (const uint16_t *)digits, n, p);
+    hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, offsets, (const uint32_t *)starts, tb);
+}
+
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
 static inline uint64_t accum_l1_lanes(uint64_t max_entries) { return (max_entries + ACC_CHUNK - 1) / ACC_CHUNK; }
 uint64_t msm_accum_workspace_slots(uint64_t max_entries) {

@@ -74,21 +74,21 @@ static Slice shard_slice(uint64_t n, uint32_t idx, uint32_t cnt) {
 struct SortBufs {
     MsmPlan plan;
     uint64_t n = 0;
-    DevBuf<uint32_t> counts, offsets, cursor, entries;
+    DevBuf<uint16_t> digits;
+    DevBuf<uint32_t> counts, starts, offsets, entries;
     uint32_t total_buckets() const { return plan.W * plan.nbuckets; }
     void alloc(uint64_t n_, uint32_t window_bits) {
         n = n_;
         plan = make_msm_plan(n ? n : 1, window_bits);
-        counts.alloc(total_buckets());
-        offsets.alloc(total_buckets() + 1 + msm_scan_extra_words(total_buckets()));
-        cursor.alloc(total_buckets());
-        entries.alloc((size_t)(n ? n : 1) * plan.W);
+        MsmSortSizes z = msm_sort_sizes(n, plan);
+        digits.alloc(z.digits_u16);
+        counts.alloc(z.counts_u32);
+        starts.alloc(z.starts_u32);
+        offsets.alloc(z.offsets_u32);
+        entries.alloc(z.entries_u32);
     }
     void run(const Fr *scalars, hipStream_t s) {
-        HIP_TRY(hipMemsetAsync(counts.p, 0, counts.n * 4, s));
-        launch_msm_count(counts.p, scalars, n, plan, s);
-        launch_msm_scan(offsets.p, cursor.p, counts.p, total_buckets(), s);
-        launch_msm_scatter(entries.p, cursor.p, scalars, n, plan, s);
+        launch_msm_sort(offsets.p, entries.p, digits.p, counts.p, starts.p, scalars, n, plan, s);
     }
 };
 
