@@ -105,10 +105,12 @@ int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta
                 const void *vk_delta2, const zk_msm_sums *partials, uint32_t n_partials,
                 const uint8_t *r32, const uint8_t *s32, zk_proof *out);
 
-/* Per-stage device times of the last prove, ms (needs ZK_FLAG_TIMINGS).  Order: see ZK_T_*. */
+/* Device times of the last prove, ms (needs ZK_FLAG_TIMINGS), from hipEvents on the library's own
+ * streams.  Two streams overlap (h chain | witness MSMs), so stage walls are not additive;
+ * the *_L1_KERNEL entries bracket exactly one launch of the level-1 accumulation kernel. */
 enum {
-    ZK_T_SPMV = 0, ZK_T_NTT, ZK_T_DIGITS_SORT, ZK_T_MSM_G1_ACCUM, ZK_T_MSM_G2_ACCUM,
-    ZK_T_MSM_REDUCE, ZK_T_TOTAL_DEVICE, ZK_T_ACCUM_LAUNCHES, ZK_T_COUNT
+    ZK_T_SPMV = 0, ZK_T_NTT, ZK_T_DIGITS_SORT, ZK_T_MSM_H, ZK_T_JOIN_WAIT, ZK_T_MSM_REDUCE,
+    ZK_T_TOTAL_DEVICE, ZK_T_G1_L1_KERNEL, ZK_T_G2_L1_KERNEL, ZK_T_COUNT
 };
 int zk_prover_timings(zk_prover *p, double *ms, uint32_t n);
 

@@ -5,7 +5,7 @@
  *
  * Follows the reference's algorithm and stage order:
  *   prove()      src/groth16.cpp:48-254   (OpenMP `parallel for` at the same seven sites
- *                :56,:66,:89,:107,:125,:144,:158; striped locks replaced by per-row ownership)
+ *                :56,:66,:89,:107,:125,:144,:158, including the 1024 striped omp locks of :63-85)
  *   file layout  src/zkey_utils.cpp:17-52, src/groth16.hpp:27-35 (44-byte packed Coef)
  * The arithmetic the reference takes from its ABSENT `depends/ffiasm` submodule
  * (.gitmodules:7-9, no pinned commit recoverable) is restated from its published algorithm:
@@ -445,21 +445,34 @@ static fe *compute_h(const oracle_zkey_view *z, const fe *wtns) {
     uint64_t n = z->domainSize;
     fe *a = (fe *)calloc(n, sizeof(fe)), *b = (fe *)calloc(n, sizeof(fe)), *c = (fe *)malloc(n * sizeof(fe));
     const coef_t *coefs = (const coef_t *)((const uint8_t *)z->coefs + 4); /* :38 */
-    /* :66-84 — the reference takes one of 1024 striped locks per record; here each thread owns
-       the rows c with c % nthreads == tid, which needs no locks and gives the same sums */
-#pragma omp parallel
-    {
-        uint32_t tid = (uint32_t)omp_get_thread_num(), nth = (uint32_t)omp_get_num_threads();
-        for (uint64_t i = 0; i < z->nCoefs; i++) {
-            coef_t rec;
-            memcpy(&rec, &coefs[i], sizeof rec);
-            if (rec.c % nth != tid) continue;
-            fe *ab = rec.m == 0 ? a : b;
-            fe aux;
-            f_mul(&FR, &aux, &wtns[rec.s], &rec.coef);
-            f_add(&FR, &ab[rec.c], &ab[rec.c], &aux);
-        }
+    /* :62-85 — exactly the reference's scheme: omp parallel for over the records, the Montgomery
+       product outside the lock, the accumulation under one of NLOCKS = 1024 locks striped by c */
+#ifdef _OPENMP
+    enum { NLOCKS = 1024 };
+    omp_lock_t locks[NLOCKS];
+    for (int i = 0; i < NLOCKS; i++) omp_init_lock(&locks[i]);
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < z->nCoefs; i++) {
+        coef_t rec;
+        memcpy(&rec, &coefs[i], sizeof rec);
+        fe *ab = rec.m == 0 ? a : b;
+        fe aux;
+        f_mul(&FR, &aux, &wtns[rec.s], &rec.coef);
+        omp_set_lock(&locks[rec.c % NLOCKS]);
+        f_add(&FR, &ab[rec.c], &ab[rec.c], &aux);
+        omp_unset_lock(&locks[rec.c % NLOCKS]);
     }
+    for (int i = 0; i < NLOCKS; i++) omp_destroy_lock(&locks[i]);
+#else
+    for (uint64_t i = 0; i < z->nCoefs; i++) {
+        coef_t rec;
+        memcpy(&rec, &coefs[i], sizeof rec);
+        fe *ab = rec.m == 0 ? a : b;
+        fe aux;
+        f_mul(&FR, &aux, &wtns[rec.s], &rec.coef);
+        f_add(&FR, &ab[rec.c], &ab[rec.c], &aux);
+    }
+#endif
 #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < n; i++) f_mul(&FR, &c[i], &a[i], &b[i]); /* :89-96 */
     int domainPower = ilog2(n);

@@ -27,16 +27,25 @@ struct Fp2T {
     ZK_HD static Fp2T sub(const Fp2T &x, const Fp2T &y) { return Fp2T{B::sub(x.a, y.a), B::sub(x.b, y.b)}; }
     ZK_HD static Fp2T neg(const Fp2T &x) { return Fp2T{B::neg(x.a), B::neg(x.b)}; }
     ZK_HD static Fp2T dbl(const Fp2T &x) { return Fp2T{B::dbl(x.a), B::dbl(x.b)}; }
-    ZK_HD static Fp2T mul(const Fp2T &x, const Fp2T &y) {   // Karatsuba: 3 base mul
-        B v0 = B::mul(x.a, y.a);
-        B v1 = B::mul(x.b, y.b);
-        B s = B::mul(B::add(x.a, x.b), B::add(y.a, y.b));
-        return Fp2T{B::sub(v0, v1), B::sub(B::sub(s, v0), v1)};
+    ZK_HD static Fp2T mul(const Fp2T &x, const Fp2T &y) {
+        if constexpr (B::FUSED_MULADD) {
+            // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u as two fused double products (field29.hpp)
+            return Fp2T{B::mul_add2(x.a, y.a, B::neg_lazy(x.b), y.b), B::mul_add2(x.a, y.b, x.b, y.a)};
+        } else {   // Karatsuba: 3 base mul
+            B v0 = B::mul(x.a, y.a);
+            B v1 = B::mul(x.b, y.b);
+            B s = B::mul(B::add(x.a, x.b), B::add(y.a, y.b));
+            return Fp2T{B::sub(v0, v1), B::sub(B::sub(s, v0), v1)};
+        }
     }
     ZK_HD static Fp2T sqr(const Fp2T &x) {                  // 2 base mul
-        B t = B::mul(x.a, x.b);
-        B c0 = B::mul(B::add(x.a, x.b), B::sub(x.a, x.b));
-        return Fp2T{c0, B::dbl(t)};
+        if constexpr (B::FUSED_MULADD) {
+            return Fp2T{B::mul(B::add(x.a, x.b), B::sub(x.a, x.b)), B::mul(B::dbl_lazy(x.a), x.b)};
+        } else {
+            B t = B::mul(x.a, x.b);
+            B c0 = B::mul(B::add(x.a, x.b), B::sub(x.a, x.b));
+            return Fp2T{c0, B::dbl(t)};
+        }
     }
     ZK_HD static Fp2T inv(const Fp2T &x) {                  // host-side only (final affine)
         B d = B::inv(B::add(B::sqr(x.a), B::sqr(x.b)));

@@ -201,6 +201,7 @@ struct Fp {
         return reduce_once(r);
     }
     ZK_HD static Fp sqr(const Fp &a) { return mul(a, a); }
+    static constexpr bool FUSED_MULADD = false;
 
     ZK_HD static Fp to_mont(const Fp &a) { return mul(a, r2()); }
     ZK_HD static Fp from_mont(const Fp &a) {

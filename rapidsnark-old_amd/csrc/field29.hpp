@@ -135,7 +135,87 @@ struct Fq29 {
         r.l[8] = (int32_t)acc;
         return r;
     }
-    ZK_HD static Fq29 sqr(const Fq29 &a) { return mul(a, a); }
+    // a^2 * 2^-261: symmetric terms once with a doubled operand — 45 product MADs instead of 81
+    ZK_HD static Fq29 sqr(const Fq29 &a) {
+        int32_t a2[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+        int64_t acc = 0;
+        int32_t m[9];
+        Fq29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; 2 * i < k; i++) acc += (int64_t)a2[i] * a.l[k - i];
+            if ((k & 1) == 0) acc += (int64_t)a.l[k >> 1] * a.l[k >> 1];
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P[k - i];
+            m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
+            acc += (int64_t)m[k] * P[0];
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; 2 * i < k; i++) acc += (int64_t)a2[i] * a.l[k - i];
+            if ((k & 1) == 0) acc += (int64_t)a.l[k >> 1] * a.l[k >> 1];
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * P[k - i];
+            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
+            acc >>= 29;
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
+    // (a*b + c*d) * 2^-261 with ONE reduction: both products share the column accumulators
+    // (|column| < 27 * 2^58 < 2^63).  The Fq2 product is two of these — same MAD count as
+    // Karatsuba but without its five add/sub + carry passes.
+    static constexpr bool FUSED_MULADD = true;
+    ZK_HD static Fq29 mul_add2(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d) {
+        int64_t acc = 0;
+        int32_t m[9];
+        Fq29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) {
+                acc += (int64_t)a.l[i] * b.l[k - i];
+                acc += (int64_t)c.l[i] * d.l[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P[k - i];
+            m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
+            acc += (int64_t)m[k] * P[0];
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) {
+                acc += (int64_t)a.l[i] * b.l[k - i];
+                acc += (int64_t)c.l[i] * d.l[k - i];
+            }
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * P[k - i];
+            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
+            acc >>= 29;
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
+    // limb-wise negation / doubling WITHOUT the carry pass: valid as one operand of a product
+    ZK_HD static Fq29 neg_lazy(const Fq29 &a) {
+        Fq29 t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.l[i] = -a.l[i];
+        return t;
+    }
+    ZK_HD static Fq29 dbl_lazy(const Fq29 &a) {
+        Fq29 t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.l[i] = a.l[i] << 1;
+        return t;
+    }
 
     // value - k*p with k = round(value / p) estimated from the two top limbs: result in (-p, p)
     ZK_HD static Fq29 reduce_near_zero(const Fq29 &a) {

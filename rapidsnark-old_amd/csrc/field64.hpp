@@ -109,6 +109,7 @@ struct Fp64 {
         return r;
     }
     static Fp64 sqr(const Fp64 &a) { return mul(a, a); }
+    static constexpr bool FUSED_MULADD = false;
     static Fp64 to_mont(const Fp64 &a) { return mul(a, r2()); }
     static Fp64 from_mont(const Fp64 &a) {
         Fp64 o = zero();

@@ -64,13 +64,14 @@ void launch_msm_sort(uint32_t *offsets, uint32_t *entries, uint16_t *digits, uin
                      const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
 // buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min.
 // max_entries: upper bound of offsets[total_buckets] (= n*W); ws_*: msm_accum_workspace_slots() slots.
+// ev (optional): two events recorded immediately before/after the level-1 kernel.
 uint64_t msm_accum_workspace_slots(uint64_t max_entries);
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         G1XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s);
+                         G1XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr);
 void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         G2XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s);
+                         G2XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr);
 // window_sums[m*W + w] = sum_k (k+1) * buckets[m][w][k]  for n_msm bucket arrays laid back to back;
 // scratch: n_msm * W * nbuckets/REDUCE_CHUNK points
 void launch_msm_reduce_g1(G1XYZZ *window_sums, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);

@@ -551,12 +551,14 @@ uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
 template <class F>
 static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries, const Affine<F> *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s) {
+                         XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev) {
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
     (void)hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s);
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
+    if (ev) (void)hipEventRecord(ev[0], s);           // tight bracket around the level-1 kernel (roofline timing)
     hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
                        points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes);
+    if (ev) (void)hipEventRecord(ev[1], s);
     uint64_t off = 0;
     while (lanes > 1) {          // a single lane has no cut runs: everything it saw was complete
         uint64_t items = 2 * lanes;
@@ -571,13 +573,13 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
 
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G1XYZZ *ws_part,
-                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s) {
-    launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s);
+                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev) {
+    launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev);
 }
 void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2XYZZ *ws_part,
-                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s) {
-    launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s);
+                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev) {
+    launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev);
 }
 
 template <class F>

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <thread>
 #include <memory>
 #include <stdexcept>
 
@@ -101,7 +102,8 @@ struct zk_prover {
     uint64_t nCoefs = 0;
     uint32_t shard_index = 0, shard_count = 1;
     uint8_t vk_alpha1[64], vk_beta1[64], vk_beta2[128], vk_delta1[64], vk_delta2[128];
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: witness-only MSM chain (A,B1,C,B2)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex mtx;
 
     // resident data
@@ -118,11 +120,11 @@ struct zk_prover {
     SortBufs sort_w, sort_h;
     DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
     DevBuf<G2XYZZ> buckets_g2;
-    DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1;
+    DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1, acc_ws_g1h;   // ...h: the H chain runs concurrently on `stream`
     DevBuf<G2XYZZ> scratch_g2, wsum_g2, acc_ws_g2;
-    DevBuf<uint32_t> acc_key, acc_flag;
+    DevBuf<uint32_t> acc_key, acc_flag, acc_key_h, acc_flag_h;
 
-    hipEvent_t ev[10];
+    hipEvent_t ev[14];
     bool have_events = false;
     double timings[ZK_T_COUNT] = {0};
     uint32_t accum_launches = 0;
@@ -130,6 +132,9 @@ struct zk_prover {
     ~zk_prover() {
         if (have_events)
             for (auto &e : ev) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -235,6 +240,9 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     memcpy(p->vk_delta2, z->vk_delta2, 128);
 
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     hipStream_t s = p->stream;
 
     // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4)
@@ -300,11 +308,14 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
         p->wsum_g2.alloc(p->sort_w.plan.W);
         uint64_t ew = (uint64_t)(nv ? nv : 1) * p->sort_w.plan.W, eh = (uint64_t)(nh ? nh : 1) * p->sort_h.plan.W;
-        uint64_t slots = msm_accum_workspace_slots(ew > eh ? ew : eh);
+        uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(eh);
         p->acc_ws_g1.alloc(slots);
-        p->acc_ws_g2.alloc(msm_accum_workspace_slots(ew));
+        p->acc_ws_g2.alloc(slots);
         p->acc_key.alloc(slots);
         p->acc_flag.alloc(slots);
+        p->acc_ws_g1h.alloc(slots_h);
+        p->acc_key_h.alloc(slots_h);
+        p->acc_flag_h.alloc(slots_h);
     }
     for (auto &e : p->ev) HIP_TRY(hipEventCreate(&e));
     p->have_events = true;
@@ -324,7 +335,25 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     };
     Fr *a = p->abc.p, *b = p->abc.p + n, *c = p->abc.p + 2 * n;
 
+    const uint32_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
+    G1XYZZ *bA = p->buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
+    const uint64_t ew = p->sort_w.n * p->sort_w.plan.W, eh = p->sort_h.n * p->sort_h.plan.W;
+    hipStream_t s2 = p->stream2;
+
     mark(0);
+    // ---- stream2: everything that depends on the witness only (the reference runs these AFTER
+    // the FFT chain, src/groth16.cpp:180-204; they are independent of it): sort(w) once, then
+    // MSM A, B1, C and B2 over the shared bucket order.  VALU-bound.
+    HIP_TRY(hipEventRecord(p->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(s2, p->ev_fork, 0));
+    p->sort_w.run(d_wtns + p->sv.lo, s2);
+    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[8] : nullptr);
+    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2);
+    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2);
+    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[10] : nullptr);
+    HIP_TRY(hipEventRecord(p->ev_join, s2));
+
+    // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
     // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96)
     CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
     launch_spmv_abc(a, b, c, csr, d_wtns, p->domainSize, s);
@@ -337,20 +366,12 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
     launch_abc_to_h(p->h.p, a, b, c, n, s);
     mark(2);
-    // digits + counting sort: once for the witness slice (shared by A,B1,B2,C), once for h
-    p->sort_w.run(d_wtns + p->sv.lo, s);
     p->sort_h.run(p->h.p + p->sh.lo, s);
     mark(3);
-    // 6-10: bucket accumulation
-    const uint32_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
-    G1XYZZ *bA = p->buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
-    const uint64_t ew = p->sort_w.n * p->sort_w.plan.W, eh = p->sort_h.n * p->sort_h.plan.W;
-    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
-    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
-    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
-    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s);
+    // 6: MSM H (src/groth16.cpp:171-173)
+    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1h.p, p->acc_key_h.p, p->acc_flag_h.p, s);
     mark(4);
-    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key.p, p->acc_flag.p, s);
+    HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
     mark(5);
     // bucket reduction -> window sums
     const uint32_t Ww = p->sort_w.plan.W, Wh = p->sort_h.plan.W;
@@ -363,26 +384,34 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     HIP_TRY(hipMemcpyAsync(w2.data(), p->wsum_g2.p, w2.size(), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (tm) {
-        float ms[7];
+        float ms[7], g1 = 0, g2 = 0;
         for (int i = 0; i < 6; i++) HIP_TRY(hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
         HIP_TRY(hipEventElapsedTime(&ms[6], p->ev[0], p->ev[6]));
+        HIP_TRY(hipEventElapsedTime(&g1, p->ev[8], p->ev[9]));
+        HIP_TRY(hipEventElapsedTime(&g2, p->ev[10], p->ev[11]));
         p->timings[ZK_T_SPMV] = ms[0];
-        p->timings[ZK_T_NTT] = ms[1];
-        p->timings[ZK_T_DIGITS_SORT] = ms[2];
-        p->timings[ZK_T_MSM_G1_ACCUM] = ms[3];
-        p->timings[ZK_T_MSM_G2_ACCUM] = ms[4];
+        p->timings[ZK_T_NTT] = ms[1];                // wall time on stream 1 (shares the GPU with stream2's MSMs)
+        p->timings[ZK_T_DIGITS_SORT] = ms[2];        // sort(h)
+        p->timings[ZK_T_MSM_H] = ms[3];              // whole MSM H accumulation on stream 1
+        p->timings[ZK_T_JOIN_WAIT] = ms[4];          // stream 1 waiting for stream2 (A,B1,C,B2)
         p->timings[ZK_T_MSM_REDUCE] = ms[5];
         p->timings[ZK_T_TOTAL_DEVICE] = ms[6];
-        p->timings[ZK_T_ACCUM_LAUNCHES] = 4;
+        p->timings[ZK_T_G1_L1_KERNEL] = g1;          // k_msm_accum_l1<Fq>  of MSM A, tight events
+        p->timings[ZK_T_G2_L1_KERNEL] = g2;          // k_msm_accum_l1<Fq2> of MSM B2, tight events
     }
     // host Horner over windows (c doublings per window)
     const uint32_t cw = p->sort_w.plan.c, ch = p->sort_h.plan.c;
     const size_t P1 = sizeof(G1XYZZ);
-    HostTail::combine_windows_g1(w1.data(), Ww, cw, out->pi_a);
-    HostTail::combine_windows_g1(w1.data() + (size_t)Ww * P1, Ww, cw, out->pib1);
-    HostTail::combine_windows_g1(w1.data() + (size_t)2 * Ww * P1, Ww, cw, out->pi_c);
-    HostTail::combine_windows_g1(w1.data() + (size_t)3 * Ww * P1, Wh, ch, out->pih);
+    // five independent serial chains (W*c doublings each): one host thread per chain
+    std::thread t1([&] { HostTail::combine_windows_g1(w1.data(), Ww, cw, out->pi_a); });
+    std::thread t2([&] { HostTail::combine_windows_g1(w1.data() + (size_t)Ww * P1, Ww, cw, out->pib1); });
+    std::thread t3([&] { HostTail::combine_windows_g1(w1.data() + (size_t)2 * Ww * P1, Ww, cw, out->pi_c); });
+    std::thread t4([&] { HostTail::combine_windows_g1(w1.data() + (size_t)3 * Ww * P1, Wh, ch, out->pih); });
     HostTail::combine_windows_g2(w2.data(), Ww, cw, out->pi_b);
+    t1.join();
+    t2.join();
+    t3.join();
+    t4.join();
 }
 
 void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {

@@ -42,7 +42,7 @@ class zk_msm_sums(C.Structure):
 
 
 ZK_FLAG_TIMINGS = 1
-ZK_T_NAMES = ["spmv", "ntt", "digits_sort", "msm_g1_accum", "msm_g2_accum", "msm_reduce", "total_device", "accum_launches"]
+ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel"]
 
 # every symbol include/zkhip.h declares (tests check the library exports all of them)
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",

@@ -40,6 +40,18 @@ __global__ void k_check(const Fq *a, const Fq *b, int n, unsigned *bad) {
     if (!W.is_zero()) f |= 256;
     if (!(x == y) && Fq29::sub(X, Y).is_zero()) f |= 512;
     if (!x.is_zero() && X.is_zero()) f |= 512;
+    // 4b. dedicated square and fused double product
+    if (!Fq29::sub(Fq29::sqr(X), Fq29::mul(X, X)).is_zero()) f |= 2048;
+    {
+        Fq29 D = Fq29::sub(X, Y), S = Fq29::add(X, Y);
+        if (!Fq29::sub(Fq29::sqr(D), Fq29::mul(D, D)).is_zero()) f |= 2048;
+        Fq29 lhs = Fq29::mul_add2(X, Y, Fq29::neg_lazy(D), S);            // xy - (x-y)(x+y)
+        Fq29 rhs = Fq29::sub(Fq29::mul(X, Y), Fq29::mul(D, S));
+        if (!Fq29::sub(lhs, rhs).is_zero()) f |= 4096;
+        Fq29 l2 = Fq29::mul_add2(D, D, S, Fq29::dbl_lazy(X));
+        Fq29 r2 = Fq29::add(Fq29::sqr(D), Fq29::mul(S, Fq29::dbl(X)));
+        if (!Fq29::sub(l2, r2).is_zero()) f |= 4096;
+    }
     // 5. load/store round trip of a canonical value
     if (!(Fq29::store(Fq29::load(x)) == x)) f |= 1024;
     if (f) atomicOr(bad, f);
