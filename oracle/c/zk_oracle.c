@@ -10,7 +10,7 @@
  * The arithmetic the reference takes from its ABSENT `depends/ffiasm` submodule
  * (.gitmodules:7-9, no pinned commit recoverable) is restated from its published algorithm:
  * 4x64-bit Montgomery (R = 2^256), radix-2 bit-reversal FFT, Pippenger multiexp with
- * per-thread bucket arrays, window = clamp(log2(n)-?, 2, 16) and Horner over windows.
+ * per-task bucket arrays (window x point-slice), window in [2,16] from a cost model, Horner over windows.
  * It is "a restatement of rapidsnark's CPU algorithm", NOT ffiasm: hand-written ADX assembly
  * may be 1.3-2x faster than this compiler-generated code (say so next to any timing).
  *
@@ -265,55 +265,65 @@ static void f2_inv(fe2 *r, const fe2 *x) {
         }                                                                                                              \
         *r = acc;                                                                                                      \
     }                                                                                                                  \
-    /* Pippenger with per-thread bucket arrays (ffiasm ParallelMultiexp shape).                                        \
-       scalars: n x 32 B LE standard form; zero scalars / zero digits / infinity bases are skipped. */                \
+    /* Pippenger with per-thread bucket arrays (ffiasm ParallelMultiexp shape), scheduled for many    \
+       cores: tasks = (window, slice of the points); every task fills its own 2^c bucket array,      \
+       slices are folded per bucket (packThreads), windows reduced by chunked running sums, then      \
+       Horner.  No per-window barriers.  scalars: n x 32 B LE standard form; zero digits and          \
+       infinity bases are skipped. */                                                                 \
     static void PFX##_msm(PFX##_jac *out, const PFX##_aff *bases, const uint8_t *scalars, uint64_t n) {                \
         PFX##_set_inf(out);                                                                                            \
         if (n == 0) return;                                                                                            \
-        int c = choose_window(n);                                                                                      \
+        int nt = omp_get_max_threads();                                                                                \
+        int c, tpw;                                                                                                    \
+        choose_plan(n, nt, &c, &tpw);                                                                                  \
         int W = (256 + c - 1) / c;                                                                                     \
         uint64_t nb = ((uint64_t)1 << c);                                                                              \
-        int nt = omp_get_max_threads();                                                                                \
-        if ((uint64_t)nt > n) nt = (int)n;                                                                             \
-        PFX##_jac *buckets = (PFX##_jac *)malloc(sizeof(PFX##_jac) * nb * (size_t)nt);                                 \
+        int ntask = W * tpw;                                                                                           \
+        PFX##_jac *buckets = (PFX##_jac *)malloc(sizeof(PFX##_jac) * nb * (size_t)ntask);                              \
         PFX##_jac *wsum = (PFX##_jac *)malloc(sizeof(PFX##_jac) * (size_t)W);                                          \
-        for (int w = 0; w < W; w++) {                                                                                  \
-            _Pragma("omp parallel num_threads(nt)")                                                                    \
-            {                                                                                                          \
-                int t = omp_get_thread_num();                                                                          \
-                PFX##_jac *B = buckets + (size_t)t * nb;                                                               \
-                memset(B, 0, sizeof(PFX##_jac) * nb);                                                                  \
-                uint64_t lo = n * (uint64_t)t / nt, hi = n * (uint64_t)(t + 1) / nt;                                   \
-                for (uint64_t i = lo; i < hi; i++) {                                                                   \
-                    uint32_t d = get_digit(scalars + i * 32, w, c);                                                    \
-                    if (d) PFX##_madd(&B[d], &B[d], &bases[i]);                                                        \
-                }                                                                                                      \
-                _Pragma("omp barrier")                                                                                 \
-                /* packThreads: fold every thread's bucket d into thread 0's */                                        \
-                _Pragma("omp for schedule(static)")                                                                    \
-                for (uint64_t d = 1; d < nb; d++)                                                                      \
-                    for (int k = 1; k < nt; k++) PFX##_add(&buckets[d], &buckets[d], &buckets[(size_t)k * nb + d]);    \
+        _Pragma("omp parallel for schedule(dynamic, 1)")                                                               \
+        for (int t = 0; t < ntask; t++) {                                                                              \
+            int w = t / tpw, j = t % tpw;                                                                              \
+            PFX##_jac *B = buckets + (size_t)t * nb;                                                                   \
+            memset(B, 0, sizeof(PFX##_jac) * nb);                                                                      \
+            uint64_t lo = n * (uint64_t)j / tpw, hi = n * (uint64_t)(j + 1) / tpw;                                     \
+            for (uint64_t i = lo; i < hi; i++) {                                                                       \
+                uint32_t d = get_digit(scalars + i * 32, w, c);                                                        \
+                if (d) PFX##_madd(&B[d], &B[d], &bases[i]);                                                            \
             }                                                                                                          \
-            /* reduce: sum_d d*B[d] by running sums, chunked across threads */                                         \
-            {                                                                                                          \
-                int parts = nt;                                                                                        \
-                if ((uint64_t)parts > nb / 4) parts = (int)(nb / 4 ? nb / 4 : 1);                                      \
-                PFX##_jac *psum = (PFX##_jac *)malloc(sizeof(PFX##_jac) * (size_t)parts);                              \
-                _Pragma("omp parallel for schedule(static) num_threads(nt)")                                           \
+        }                                                                                                              \
+        /* packThreads: fold slices 1.. into slice 0, per (window, bucket) */                                          \
+        if (tpw > 1) {                                                                                                 \
+            _Pragma("omp parallel for schedule(static) collapse(2)")                                                   \
+            for (int w = 0; w < W; w++)                                                                                \
+                for (uint64_t d = 1; d < nb; d++) {                                                                    \
+                    PFX##_jac *B0 = buckets + (size_t)(w * tpw) * nb;                                                  \
+                    for (int j = 1; j < tpw; j++) PFX##_add(&B0[d], &B0[d], &buckets[(size_t)(w * tpw + j) * nb + d]); \
+                }                                                                                                      \
+        }                                                                                                              \
+        /* reduce: sum_d d*B[d] by running sums, chunked (parts per window) */                                         \
+        {                                                                                                              \
+            int parts = (nt + W - 1) / W;                                                                              \
+            if ((uint64_t)parts > nb / 4) parts = (int)(nb / 4 ? nb / 4 : 1);                                          \
+            PFX##_jac *psum = (PFX##_jac *)malloc(sizeof(PFX##_jac) * (size_t)parts * W);                              \
+            _Pragma("omp parallel for schedule(dynamic, 1) collapse(2)")                                               \
+            for (int w = 0; w < W; w++)                                                                                \
                 for (int k = 0; k < parts; k++) {                                                                      \
+                    const PFX##_jac *B0 = buckets + (size_t)(w * tpw) * nb;                                            \
                     uint64_t lo = 1 + (nb - 1) * (uint64_t)k / parts, hi = 1 + (nb - 1) * (uint64_t)(k + 1) / parts;   \
                     PFX##_jac run, sum; PFX##_set_inf(&run); PFX##_set_inf(&sum);                                      \
-                    for (uint64_t d = hi; d-- > lo;) { PFX##_add(&run, &run, &buckets[d]); PFX##_add(&sum, &sum, &run); } \
+                    for (uint64_t d = hi; d-- > lo;) { PFX##_add(&run, &run, &B0[d]); PFX##_add(&sum, &sum, &run); }   \
                     /* sum = sum_{d in [lo,hi)} (d-lo+1) B[d]; add (lo-1)*run */                                       \
                     uint8_t kk[32] = {0}; uint64_t m = lo - 1; memcpy(kk, &m, 8);                                      \
                     PFX##_jac mr; PFX##_mul_scalar(&mr, &run, kk); PFX##_add(&sum, &sum, &mr);                         \
-                    psum[k] = sum;                                                                                     \
+                    psum[w * parts + k] = sum;                                                                         \
                 }                                                                                                      \
+            for (int w = 0; w < W; w++) {                                                                              \
                 PFX##_jac tot; PFX##_set_inf(&tot);                                                                    \
-                for (int k = 0; k < parts; k++) PFX##_add(&tot, &tot, &psum[k]);                                       \
+                for (int k = 0; k < parts; k++) PFX##_add(&tot, &tot, &psum[w * parts + k]);                           \
                 wsum[w] = tot;                                                                                         \
-                free(psum);                                                                                            \
             }                                                                                                          \
+            free(psum);                                                                                                \
         }                                                                                                              \
         PFX##_jac acc; PFX##_set_inf(&acc);                                                                            \
         for (int w = W - 1; w >= 0; w--) {                                                                             \
@@ -324,18 +334,23 @@ static void f2_inv(fe2 *r, const fe2 *x) {
         free(buckets); free(wsum);                                                                                     \
     }
 
-/* window bits: ffiasm-style clamp(log2(n) - 2?, 2, 16); tuned down a little so the per-thread
- * bucket arrays (threads x 2^c x 96 B) stay cache-friendly */
-static int choose_window(uint64_t n) {
-    int lg = 0;
-    while (((uint64_t)1 << (lg + 1)) <= n) lg++;
-    int nt = omp_get_max_threads();
-    int ltn = 0;
-    while ((1 << (ltn + 1)) <= nt) ltn++;
-    int c = lg - ltn - 3;            /* ~8+ points per bucket per thread */
-    if (c < 2) c = 2;
-    if (c > 16) c = 16;
-    return c;
+/* window bits c (ffiasm clamps to [2,16]) and slices-per-window from a cost model in point
+ * additions: W * (n [accumulate] + tpw * 2^c [fold slices] + 2 * 2^c [running sums]) */
+static void choose_plan(uint64_t n, int nt, int *c_out, int *tpw_out) {
+    double best = 1e300;
+    int bc = 2, bt = 1;
+    for (int c = 2; c <= 16; c++) {
+        int W = (256 + c - 1) / c;
+        int tpw = nt / W;
+        if (tpw < 1) tpw = 1;
+        if ((uint64_t)tpw > n) tpw = (int)n;
+        double nb = (double)((uint64_t)1 << c);
+        int par = W * tpw < nt ? W * tpw : nt;
+        double cost = W * ((double)n + (tpw > 1 ? tpw * nb : 0.0) + 2.0 * nb) / par + 2.0 * nb / 4.0;
+        if (cost < best) { best = cost; bc = c; bt = tpw; }
+    }
+    *c_out = bc;
+    *tpw_out = bt;
 }
 /* unsigned c-bit digit w of a 256-bit LE scalar */
 static inline uint32_t get_digit(const uint8_t *s, int w, int c) {
@@ -552,6 +567,13 @@ static void final_assembly(const oracle_zkey_view *z, const oracle_msm_sums *m, 
 
 /* ------------------------------------------------------------------ exported C API (ctypes) */
 int oracle_num_threads(void) { return omp_get_max_threads(); }
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 void oracle_fr_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n) {
 #pragma omp parallel for schedule(static)

@@ -45,6 +45,8 @@ def load(path=None):
     lib = C.CDLL(p)
     v = C.c_void_p
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_set_num_threads.argtypes = [C.c_int]
+    lib.oracle_set_num_threads.restype = None
     for n in ("oracle_fr_mul_vec", "oracle_fq_mul_vec"):
         getattr(lib, n).argtypes = [v, v, v, C.c_uint64]
         getattr(lib, n).restype = None
@@ -80,6 +82,10 @@ def _p(a):
 
 def num_threads():
     return load().oracle_num_threads()
+
+
+def set_num_threads(n):
+    load().oracle_set_num_threads(int(n))
 
 
 def fr_mul_vec(a, b):
