@@ -22,15 +22,35 @@
 
 namespace zk {
 
-struct Fq29 {
-    int32_t l[9];
-
-    static constexpr int32_t MASK = (1 << 29) - 1;
+struct Fq29Params {
+    typedef Fq Words;   // the 8x32-bit container of the same field (HBM format)
     static constexpr int32_t P[9] = {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406};
     static constexpr uint32_t N0INV = 75916169u;   // -p^-1 mod 2^29
     static constexpr int32_t ONE[9] = {360500257, 337389400, 408039635, 21759001, 178483129, 490881230, 299191303, 86689704, 903222};      // 2^261 mod p
     static constexpr int32_t K_IN[9] = {322215073, 442336424, 171859116, 268585440, 314135016, 244503300, 348886451, 68918589, 360451};    // 2^266 mod p
     static constexpr int32_t K_OUT[9] = {93261213, 451550318, 297979764, 299258347, 342016167, 297253948, 482187706, 406012155, 920183};   // 2^256 mod p
+};
+struct Fr29Params {
+    typedef Fr Words;
+    static constexpr int32_t P[9] = {268435457, 521120927, 240919632, 131109107, 361091715, 47923392, 10936641, 240920116, 3171406};
+    static constexpr uint32_t N0INV = 268435455u;  // -r^-1 mod 2^29
+    static constexpr int32_t ONE[9] = {268435287, 514263732, 86771339, 391139145, 178784091, 490881230, 299191303, 86689704, 903222};       // 2^261 mod r
+    static constexpr int32_t K_IN[9] = {268430039, 492061940, 71535269, 62181526, 323781850, 244503300, 348886451, 68918589, 360451};      // 2^266 mod r
+    static constexpr int32_t K_OUT[9] = {268435451, 78749922, 406014571, 418196286, 342025071, 297253948, 482187706, 406012155, 920183};   // 2^256 mod r
+};
+
+template <class PR>
+struct Fp29 {
+    int32_t l[9];
+    typedef typename PR::Words Words;
+    typedef Fp29 Fq29;   // (keeps the member bodies below readable: "Fq29" = this instantiation)
+
+    static constexpr int32_t MASK = (1 << 29) - 1;
+    static constexpr const int32_t (&P)[9] = PR::P;
+    static constexpr uint32_t N0INV = PR::N0INV;
+    static constexpr const int32_t (&ONE)[9] = PR::ONE;
+    static constexpr const int32_t (&K_IN)[9] = PR::K_IN;
+    static constexpr const int32_t (&K_OUT)[9] = PR::K_OUT;
 
     ZK_HD static Fq29 zero() {
         Fq29 r;
@@ -219,7 +239,8 @@ struct Fq29 {
 
     // value - k*p with k = round(value / p) estimated from the two top limbs: result in (-p, p)
     ZK_HD static Fq29 reduce_near_zero(const Fq29 &a) {
-        // p >> 203 = 1702635872462388 ; (l8, l7) = value >> 203 up to the low limbs' slack
+        // p >> 203 = 1702635872462388 for both BN254 primes (they share their top 128 bits);
+        // (l8, l7) = value >> 203 up to the low limbs' slack
         float vt = (float)a.l[8] * 536870912.0f + (float)a.l[7];
         int32_t k = (int32_t)__builtin_rintf(vt * (1.0f / 1702635872462388.0f));
         Fq29 t;
@@ -278,19 +299,28 @@ struct Fq29 {
         w[7] = (l7 >> 21) | (l8 << 8);
     }
     // zkey form x*2^256 (canonical words)  <->  internal x*2^261
-    ZK_HD static Fq29 from_mont256(const Fq &x) { return mul(from_words(x.v), k_in()); }
-    ZK_HD static Fq to_mont256(const Fq29 &x) {
-        Fq r;
+    ZK_HD static Fq29 from_mont256(const Words &x) { return mul(from_words(x.v), k_in()); }
+    ZK_HD static Words to_mont256(const Fq29 &x) {
+        Words r;
         to_words(r.v, canonical(mul(x, k_out())));
         return r;
     }
     // internal value <-> canonical words of the SAME Montgomery form (HBM residency format)
-    ZK_HD static Fq29 load(const Fq &x) { return from_words(x.v); }
-    ZK_HD static Fq store(const Fq29 &x) {
-        Fq r;
+    ZK_HD static Fq29 load(const Words &x) { return from_words(x.v); }
+    ZK_HD static Words store(const Fq29 &x) {
+        Words r;
         to_words(r.v, canonical(x));
         return r;
     }
+    // value * 2^-261: leaves Montgomery form (standard-form result, e.g. MSM scalars)
+    ZK_HD static Fq29 from_mont(const Fq29 &a) {
+        Fq29 o = zero();
+        o.l[0] = 1;
+        return mul(a, o);
+    }
 };
+
+typedef Fp29<Fq29Params> Fq29;
+typedef Fp29<Fr29Params> Fr29;
 
 }   // namespace zk

@@ -1,5 +1,6 @@
 // Pointwise Fr/Fq kernels and the sparse A.w / B.w accumulation (src/groth16.cpp:56-96).
 #include "kernels.hpp"
+#include "field29.hpp"
 
 namespace zk {
 
@@ -42,27 +43,33 @@ void launch_fq_mul_vec(Fq *out, const Fq *a, const Fq *b, uint64_t n, hipStream_
 
 // One lane per domain row i: a[i] = sum_A coef*w[s], b[i] = sum_B coef*w[s], c[i] = a[i]*b[i].
 // The reference does this with 1024 striped omp locks (src/groth16.cpp:63-84); a row-sorted
-// CSR built once at create time needs neither locks nor atomics.  coef is the zkey's
-// value*R^2, w is standard form, so the Montgomery product is the Montgomery form of w*value.
+// CSR built once at create time needs neither locks nor atomics.  The zkey stores
+// value*2^512; create rescales it to value*2^522 so that one 2^-261 Montgomery product with
+// the standard-form witness gives w*value in this library's 2^261 form (field29.hpp).
 __global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr acc[2];
+    Fr29 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; m++) {
         uint32_t row = i + (m ? n : 0);
         uint32_t lo = csr.rowptr[row], hi = csr.rowptr[row + 1];
-        Fr sum = Fr::zero();
+        Fr29 sum = Fr29::zero();
+        uint32_t pending = 0;
         for (uint32_t k = lo; k < hi; k++) {
-            Fr w = load_el(wtns + csr.col[k]);
-            Fr v = load_el(csr.val + k);
-            sum = Fr::add(sum, Fr::mul(w, v));
+            Fr29 w = Fr29::load(load_el(wtns + csr.col[k]));       // standard form, < r for well-formed files
+            Fr29 v = Fr29::load(load_el(csr.val + k));             // value * 2^522 (pre-scaled at create)
+            sum = Fr29::add(sum, Fr29::mul(w, v));                 // += w*value * 2^261
+            if (++pending == 8) {                                  // long rows: keep the lazy sum small
+                sum = Fr29::reduce_near_zero(sum);
+                pending = 0;
+            }
         }
-        acc[m] = sum;
+        acc[m] = Fr29::reduce_near_zero(sum);
     }
-    store_el(a + i, acc[0]);
-    store_el(b + i, acc[1]);
-    store_el(c + i, Fr::mul(acc[0], acc[1]));
+    store_el(a + i, Fr29::store(acc[0]));
+    store_el(b + i, Fr29::store(acc[1]));
+    store_el(c + i, Fr29::store(Fr29::mul(acc[0], acc[1])));
 }
 
 void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s) {

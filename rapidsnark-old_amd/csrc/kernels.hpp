@@ -24,7 +24,7 @@ void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n
 // ---------------------------------------------------------------- ntt.hip
 struct NttTables {
     uint32_t logn;       // domain size 2^logn
-    const Fr *fwd;       // w_n^k,  k < n/2   (Montgomery)
+    const Fr *fwd;       // w_n^k,  k < n/2   (all tables: canonical words of the 2^261 Montgomery form)
     const Fr *inv;       // w_n^-k, k < n/2
     const Fr *coset;     // n^-1 * w_2n^brev(p) for position p < n  (bit-reversed order)
     const Fr *ninv;      // single element n^-1 (Montgomery)
@@ -35,7 +35,12 @@ void launch_ntt_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv, uint32_t log
 //  dif_inverse: natural -> bit-reversed, inverse twiddles, NO scaling
 //  dit_forward: bit-reversed -> natural, forward twiddles
 void launch_ntt_dif_inverse(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s);
-void launch_ntt_dit_forward(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s);
+// premul (optional): table multiplied in as the first pass loads (the fused coset*1/n shift)
+void launch_ntt_dit_forward(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s, const Fr *premul = nullptr);
+// Fr vectors: x*2^256 (zkey/ffiasm Montgomery form) -> x*2^(256+5*times) ; and 2^261 -> 2^256.
+// The NTT / SpMV kernels work on canonical words of the 2^261 form (field29.hpp).
+void launch_fr_to_internal(Fr *x, uint64_t n, int times, hipStream_t s);
+void launch_fr_from_internal(Fr *x, uint64_t n, hipStream_t s);
 // x[p] *= table[p]  (coset shift fused with 1/n, src/groth16.cpp:107-110)
 void launch_fr_scale_by_table(Fr *data, uint64_t stride_elems, uint32_t batch, const Fr *table, uint64_t n, hipStream_t s);
 // x[p] *= k ; and natural<->bit-reversed permutation (operator-level zk_fr_ntt only)

@@ -303,8 +303,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 //     edge to its TAIL slot (at most one of each), tagged with its bucket and STARTS/ENDS flags;
 //   * the slot list (2 per lane, still bucket-sorted) is reduced by the same algorithm with
 //     XYZZ inputs (k_msm_accum_ln), shrinking ~ACC_CHUNK_N/2 per level until one lane is left.
-// Work per lane is constant, so the kernel time is flat in the scalar distribution.
-#define ACC_CHUNK 128u      // affine points per lane, level 1
+// Work per lane is constant, so the kernel time is flat in the scalar distribution.  The chunk
+// is 128 entries, halved (to 32) for small or sharded MSMs so every SIMD still gets ~3 waves.
+#define ACC_CHUNK_MAX 128u  // affine points per lane, level 1 (halved until >= ~3 waves/SIMD of lanes exist)
+#define ACC_CHUNK_MIN 32u
 #define ACC_CHUNK_N 32u     // slots per lane, levels >= 2
 #define SLOT_EMPTY 0xffffffffu
 #define FLAG_STARTS 1u
@@ -314,7 +316,7 @@ template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                       const Affine<F> *points, uint32_t idx_min, uint32_t idx_sub,
                                                       uint32_t nbuckets_total, XYZZ<F> *out_part, uint32_t *out_key,
-                                                      uint32_t *out_flag, uint32_t nlanes) {
+                                                      uint32_t *out_flag, uint32_t nlanes, uint32_t ACC_CHUNK) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nlanes) return;
     const uint32_t E = offsets[nbuckets_total];
@@ -382,6 +384,27 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
     out_flag[2 * (uint64_t)t] = hflag;
     out_key[2 * (uint64_t)t + 1] = tkey;
     out_flag[2 * (uint64_t)t + 1] = tflag;
+}
+
+// Pairwise merge between level 1 and the generic levels: a bucket cut by exactly ONE chunk edge
+// (the overwhelmingly common case — mean run length ~ chunk length) is the TAIL slot of lane t
+// plus the HEAD slot of lane t+1 that also ENDS.  One general add per lane, full occupancy,
+// and both slots are retired; what is left for the serial-ish generic levels is only the
+// buckets spanning three or more chunks (top window, skewed witnesses).
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_accum_pair(XYZZ<F> *buckets, const XYZZ<F> *part, uint32_t *key, const uint32_t *flag,
+                                                        uint32_t nlanes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t + 1 >= nlanes) return;
+    const uint32_t kt = key[2 * (uint64_t)t + 1], kh = key[2 * (uint64_t)t + 2];
+    if (kt == SLOT_EMPTY || kt != kh) return;
+    if (!(flag[2 * (uint64_t)t + 2] & FLAG_ENDS)) return;       // continues further: generic levels
+    typedef REGF FR;
+    XYZZ<FR> a = load_xyzz(part + 2 * (uint64_t)t + 1);
+    add(a, load_xyzz(part + 2 * (uint64_t)t + 2));
+    store_xyzz(buckets + kt, a);
+    key[2 * (uint64_t)t + 1] = SLOT_EMPTY;
+    key[2 * (uint64_t)t + 2] = SLOT_EMPTY;
 }
 
 // Levels >= 2: the same chunked segmented sum over a bucket-sorted slot list of XYZZ partials.
@@ -535,7 +558,15 @@ void launch_msm_sort(uint32_t *offsets, uint32_t *entries, uint16_t *digits, uin
 }
 
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
-static inline uint64_t accum_l1_lanes(uint64_t max_entries) { return (max_entries + ACC_CHUNK - 1) / ACC_CHUNK; }
+static inline uint32_t accum_chunk_for(uint64_t max_entries) {
+    uint32_t chunk = ACC_CHUNK_MAX;
+    while (chunk > ACC_CHUNK_MIN && max_entries / chunk < 3u * 1024u * 64u) chunk >>= 1;   // 256 CUs x 4 SIMDs x 3 waves
+    return chunk;
+}
+static inline uint64_t accum_l1_lanes(uint64_t max_entries) {
+    uint32_t chunk = accum_chunk_for(max_entries);
+    return (max_entries + chunk - 1) / chunk;
+}
 uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
     uint64_t total = 0;
@@ -557,8 +588,12 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
     if (ev) (void)hipEventRecord(ev[0], s);           // tight bracket around the level-1 kernel (roofline timing)
     hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
-                       points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes);
+                       points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
+                       accum_chunk_for(max_entries ? max_entries : 1));
     if (ev) (void)hipEventRecord(ev[1], s);
+    if (lanes > 1)
+        hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets,
+                           (const XYZZ<F> *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
     uint64_t off = 0;
     while (lanes > 1) {          // a single lane has no cut runs: everything it saw was complete
         uint64_t items = 2 * lanes;

@@ -11,8 +11,12 @@
 //     gather 2^q-element contiguous runs (>= 256 B) so HBM accesses stay coalesced.
 //     2^22 points = 3 launches instead of 22 sweeps.
 //   * a/b/c are transformed in one launch (blockIdx.y).
+//   * arithmetic: 9x29-bit signed limbs (field29.hpp, 2x the Montgomery-product rate of the 8x32
+//     form); HBM keeps canonical 256-bit words in the 2^261 Montgomery form, LDS holds 9 limb planes
+//     (72 KiB per 2048-element tile); the coset*1/n table is applied as the first DIT pass loads.
 // The butterflies are Montgomery-multiply bound (VALU), see DESIGN.md.
 #include "kernels.hpp"
+#include "field29.hpp"
 
 namespace zk {
 
@@ -35,15 +39,15 @@ __device__ __forceinline__ void store_el(F *p, const F &r) {
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
 
-__device__ __forceinline__ Fr lds_get(const uint32_t *lds, uint32_t N, uint32_t e) {
-    Fr r;
+__device__ __forceinline__ Fr29 lds_get(const int32_t *lds, uint32_t N, uint32_t e) {
+    Fr29 r;
 #pragma unroll
-    for (int l = 0; l < 8; l++) r.v[l] = lds[l * N + e];
+    for (int l = 0; l < 9; l++) r.l[l] = lds[l * N + e];
     return r;
 }
-__device__ __forceinline__ void lds_put(uint32_t *lds, uint32_t N, uint32_t e, const Fr &r) {
+__device__ __forceinline__ void lds_put(int32_t *lds, uint32_t N, uint32_t e, const Fr29 &r) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) lds[l * N + e] = r.v[l];
+    for (int l = 0; l < 9; l++) lds[l * N + e] = r.l[l];
 }
 
 // One pass over index bits [lo, lo+t): 2^t rows x 2^q contiguous columns per workgroup.
@@ -51,10 +55,13 @@ __device__ __forceinline__ void lds_put(uint32_t *lds, uint32_t N, uint32_t e, c
 //   DIT : stages from bit lo up to lo+t-1:    (u,v) -> (u+v*w, u-v*w)
 // w = tw[j << (logn-1-b)] = w_n^(j*n/2^(b+1)), j = low b bits of the element index.
 // premul (optional): element i is multiplied by premul[i] as it is loaded.
+// Lazy ranges (field29.hpp): a DIT value grows by < 1.2p per stage (11 stages: < 15p, and only
+// ever meets a canonical twiddle in a product); the DIF sum u+v would double per stage, so it is
+// pulled back to (-p/2, p/2) each stage.  Stores canonicalise.
 template <bool DIF>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t stride_elems, const Fr *tw, const Fr *premul,
                                                           uint32_t logn, uint32_t lo, uint32_t t, uint32_t q) {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ int32_t lds[];
     const uint32_t T = t + q, N = 1u << T;
     Fr *x = data + (uint64_t)blockIdx.y * stride_elems;
     const uint32_t tile = blockIdx.x;
@@ -66,8 +73,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t str
 
     for (uint32_t e = threadIdx.x; e < N; e += NTT_THREADS) {
         uint64_t i = base | ((uint64_t)(e >> q) << lo) | (e & cmask);
-        Fr v = load_el(x + i);
-        if (premul) v = Fr::mul(v, load_el(premul + i));
+        Fr29 v = Fr29::load(load_el(x + i));
+        if (premul) v = Fr29::mul(v, Fr29::load(load_el(premul + i)));
         lds_put(lds, N, e, v);
     }
     __syncthreads();
@@ -83,20 +90,20 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t str
             uint32_t e0 = (r0 << q) | c;
             uint32_t e1 = e0 + (1u << (rb + q));
             uint64_t j = ((uint64_t)(r0 & rmask) << lo) | (mid << q) | c;
-            Fr u = lds_get(lds, N, e0), v = lds_get(lds, N, e1);
-            Fr s0, s1;
+            Fr29 u = lds_get(lds, N, e0), v = lds_get(lds, N, e1);
+            Fr29 s0, s1;
             if (b == 0) {                       // w = 1
-                s0 = Fr::add(u, v);
-                s1 = Fr::sub(u, v);
+                s0 = Fr29::add(u, v);
+                s1 = Fr29::sub(u, v);
             } else {
-                Fr w = load_el(tw + (j << tshift));
+                Fr29 w = Fr29::load(load_el(tw + (j << tshift)));
                 if (DIF) {
-                    s0 = Fr::add(u, v);
-                    s1 = Fr::mul(Fr::sub(u, v), w);
+                    s0 = Fr29::reduce_near_zero(Fr29::add(u, v));
+                    s1 = Fr29::mul(Fr29::sub(u, v), w);
                 } else {
-                    v = Fr::mul(v, w);
-                    s0 = Fr::add(u, v);
-                    s1 = Fr::sub(u, v);
+                    v = Fr29::mul(v, w);
+                    s0 = Fr29::add(u, v);
+                    s1 = Fr29::sub(u, v);
                 }
             }
             lds_put(lds, N, e0, s0);
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t str
 
     for (uint32_t e = threadIdx.x; e < N; e += NTT_THREADS) {
         uint64_t i = base | ((uint64_t)(e >> q) << lo) | (e & cmask);
-        store_el(x + i, lds_get(lds, N, e));
+        store_el(x + i, Fr29::store(lds_get(lds, N, e)));
     }
 }
 
@@ -144,7 +151,13 @@ static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const Fr *tw, co
                      uint32_t lo, uint32_t t, uint32_t q, hipStream_t s) {
     uint32_t T = t + q;
     uint32_t tiles = 1u << (logn - T);
-    size_t shmem = (size_t)32 << T;
+    size_t shmem = (size_t)36 << T;     // 9 limb planes; 72 KiB at T = 11 (opt-in above 64 KiB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k_ntt_pass<DIF>, dim3(tiles, batch), dim3(NTT_THREADS), shmem, s, data, stride, tw, premul, logn, lo, t, q);
 }
 
@@ -154,10 +167,14 @@ void launch_ntt_dif_inverse(Fr *data, uint64_t stride, uint32_t batch, const Ntt
     for (int i = p.n - 1; i >= 0; i--) run_pass<true>(data, stride, batch, tb.inv, nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
 }
 
-void launch_ntt_dit_forward(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s) {
-    if (tb.logn == 0) return;
+void launch_ntt_dit_forward(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s, const Fr *premul) {
+    if (tb.logn == 0) {
+        if (premul) launch_fr_scale_by_table(data, stride, batch, premul, 1, s);
+        return;
+    }
     PassPlan p = plan_passes(tb.logn);
-    for (int i = 0; i < p.n; i++) run_pass<false>(data, stride, batch, tb.fwd, nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
+    for (int i = 0; i < p.n; i++)
+        run_pass<false>(data, stride, batch, tb.fwd, i == 0 ? premul : nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
 }
 
 // ------------------------------------------------------------------ pointwise helpers
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(256) void k_scale_table(Fr *data, uint64_t stride_e
     Fr *x = data + (uint64_t)blockIdx.y * stride_elems;
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st)
-        store_el(x + i, Fr::mul(load_el(x + i), load_el(table + i)));
+        store_el(x + i, Fr29::store(Fr29::mul(Fr29::load(load_el(x + i)), Fr29::load(load_el(table + i)))));
 }
 void launch_fr_scale_by_table(Fr *data, uint64_t stride, uint32_t batch, const Fr *table, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
@@ -174,10 +191,10 @@ void launch_fr_scale_by_table(Fr *data, uint64_t stride, uint32_t batch, const F
 }
 
 __global__ __launch_bounds__(256) void k_scale_const(Fr *x, const Fr *k, uint64_t n) {
-    Fr kk = load_el(k);
+    Fr29 kk = Fr29::load(load_el(k));
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st)
-        store_el(x + i, Fr::mul(load_el(x + i), kk));
+        store_el(x + i, Fr29::store(Fr29::mul(Fr29::load(load_el(x + i)), kk)));
 }
 void launch_fr_scale_const(Fr *data, const Fr *k, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
@@ -210,14 +227,41 @@ void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
-        Fr t = Fr::sub(Fr::mul(load_el(a + i), load_el(b + i)), load_el(c + i));
-        store_el(h + i, Fr::from_mont(t));
+        Fr29 t = Fr29::sub(Fr29::mul(Fr29::load(load_el(a + i)), Fr29::load(load_el(b + i))), Fr29::load(load_el(c + i)));
+        store_el(h + i, Fr29::store(Fr29::from_mont(t)));
     }
 }
 void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_abc_to_h, dim3((uint32_t)g), dim3(256), 0, s, h, a, b, c, n);
+}
+
+// x*2^256 (the reference's Montgomery form) <-> x*2^261 (this library's internal form), in place
+__global__ __launch_bounds__(256) void k_fr_convert(Fr *x, uint64_t n, int to_internal, int times) {
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        Fr v = load_el(x + i);
+        if (to_internal) {
+            Fr29 t = Fr29::from_mont256(v);
+            for (int k = 1; k < times; k++) t = Fr29::mul(t, Fr29::k_in());     // each extra round is another * 2^5
+            store_el(x + i, Fr29::store(t));
+        } else {
+            store_el(x + i, Fr29::to_mont256(Fr29::load(v)));
+        }
+    }
+}
+void launch_fr_to_internal(Fr *x, uint64_t n, int times, hipStream_t s) {
+    if (!n) return;
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 1, times);
+}
+void launch_fr_from_internal(Fr *x, uint64_t n, hipStream_t s) {
+    if (!n) return;
+    uint64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 0, 1);
 }
 
 // ------------------------------------------------------------------ twiddle tables
@@ -265,13 +309,13 @@ __global__ __launch_bounds__(256) void k_build_tables(Fr *fwd, Fr *inv, Fr *cose
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
         if (i < (n >> 1) || n == 1) {
             if (n > 1) {
-                store_el(fwd + i, fr_pow(s_wn, i));
-                store_el(inv + i, fr_pow(s_wninv, i));
+                store_el(fwd + i, Fr29::store(Fr29::from_mont256(fr_pow(s_wn, i))));
+                store_el(inv + i, Fr29::store(Fr29::from_mont256(fr_pow(s_wninv, i))));
             }
         }
         uint32_t k = brev((uint32_t)i, logn);
-        store_el(coset + i, Fr::mul(fr_pow(s_w2n, k), s_ninv));
-        if (i == 0) store_el(ninv_out, s_ninv);
+        store_el(coset + i, Fr29::store(Fr29::from_mont256(Fr::mul(fr_pow(s_w2n, k), s_ninv))));
+        if (i == 0) store_el(ninv_out, Fr29::store(Fr29::from_mont256(s_ninv)));
     }
 }
 

@@ -255,6 +255,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->csr_rowptr.upload(rowptr.data(), rowptr.size(), s);
     p->csr_col.upload(col.data(), col.size(), s);
     p->csr_val.upload(val.data(), col.size(), s);
+    launch_fr_to_internal(p->csr_val.p, col.size(), 2, s);      // value*2^512 -> value*2^522 (see k_spmv_abc)
 
     // --- twiddles
     p->tw_fwd.alloc(n > 1 ? n / 2 : 1);
@@ -361,8 +362,7 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     // 4: three coset evaluations (src/groth16.cpp:98-155), batched, no bit-reversal pass
     NttTables tb{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p};
     launch_ntt_dif_inverse(p->abc.p, n, 3, tb, s);
-    launch_fr_scale_by_table(p->abc.p, n, 3, p->tw_coset.p, n, s);
-    launch_ntt_dit_forward(p->abc.p, n, 3, tb, s);
+    launch_ntt_dit_forward(p->abc.p, n, 3, tb, s, p->tw_coset.p);     // coset shift * 1/n fused into the first pass
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
     launch_abc_to_h(p->h.p, a, b, c, n, s);
     mark(2);
@@ -558,6 +558,7 @@ int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse) {
         DevBuf<Fr> d;
         d.alloc(n);
         d.upload(data, n, 0);
+        launch_fr_to_internal(d.p, n, 1, 0);          // x*2^256 -> x*2^261
         if (inverse) {
             launch_ntt_dif_inverse(d.p, n, 1, tb.t, 0);
             launch_bitrev_permute(d.p, logn, 0);
@@ -566,6 +567,7 @@ int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse) {
             launch_bitrev_permute(d.p, logn, 0);
             launch_ntt_dit_forward(d.p, n, 1, tb.t, 0);
         }
+        launch_fr_from_internal(d.p, n, 0);
         HIP_TRY(hipMemcpy(data, d.p, n * 32, hipMemcpyDeviceToHost));
     });
 }
@@ -582,10 +584,10 @@ int zk_fr_abc_to_h(uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n) {
         hh.alloc(n);
         HIP_TRY(hipMemcpy(abc.p, a, n * 32, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(abc.p + n, b, n * 32, hipMemcpyHostToDevice));
-        launch_fr_mul_vec(abc.p + 2 * n, abc.p, abc.p + n, n, 0);
+        launch_fr_mul_vec(abc.p + 2 * n, abc.p, abc.p + n, n, 0);      // c = a o b in the reference's form
+        launch_fr_to_internal(abc.p, 3 * n, 1, 0);
         launch_ntt_dif_inverse(abc.p, n, 3, tb.t, 0);
-        launch_fr_scale_by_table(abc.p, n, 3, tb.coset.p, n, 0);
-        launch_ntt_dit_forward(abc.p, n, 3, tb.t, 0);
+        launch_ntt_dit_forward(abc.p, n, 3, tb.t, 0, tb.coset.p);
         launch_abc_to_h(hh.p, abc.p, abc.p + n, abc.p + 2 * n, n, 0);
         HIP_TRY(hipMemcpy(h, hh.p, n * 32, hipMemcpyDeviceToHost));
     });
