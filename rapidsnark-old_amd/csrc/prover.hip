@@ -103,7 +103,7 @@ struct zk_prover {
     uint32_t shard_index = 0, shard_count = 1;
     uint8_t vk_alpha1[64], vk_beta1[64], vk_beta2[128], vk_delta1[64], vk_delta2[128];
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: witness-only MSM chain (A,B1,C,B2)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr;
     std::mutex mtx;
 
     // resident data
@@ -134,6 +134,7 @@ struct zk_prover {
             for (auto &e : ev) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_sortw) (void)hipEventDestroy(ev_sortw);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -243,6 +244,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_sortw, hipEventDisableTiming));
     hipStream_t s = p->stream;
 
     // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4)
@@ -309,7 +311,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
         p->wsum_g2.alloc(p->sort_w.plan.W);
         uint64_t ew = (uint64_t)(nv ? nv : 1) * p->sort_w.plan.W, eh = (uint64_t)(nh ? nh : 1) * p->sort_h.plan.W;
-        uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(eh);
+        uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(ew > eh ? ew : eh);   // stream 1 runs H and C
         p->acc_ws_g1.alloc(slots);
         p->acc_ws_g2.alloc(slots);
         p->acc_key.alloc(slots);
@@ -342,16 +344,21 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     hipStream_t s2 = p->stream2;
 
     mark(0);
-    // ---- stream2: everything that depends on the witness only (the reference runs these AFTER
-    // the FFT chain, src/groth16.cpp:180-204; they are independent of it): sort(w) once, then
-    // MSM A, B1, C and B2 over the shared bucket order.  VALU-bound.
+    // ---- stream2: work that depends on the witness only (the reference runs it AFTER the FFT
+    // chain, src/groth16.cpp:180-204; it is independent of it): sort(w) once, then MSM B2, A, B1
+    // over the shared bucket order.  MSM C joins stream 1 behind MSM H to balance the streams.
     HIP_TRY(hipEventRecord(p->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(s2, p->ev_fork, 0));
     p->sort_w.run(d_wtns + p->sv.lo, s2);
+    HIP_TRY(hipEventRecord(p->ev_sortw, s2));
+    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[10] : nullptr);
     launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[8] : nullptr);
     launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2);
-    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2);
-    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[10] : nullptr);
+    // bucket reductions stay on the stream of their MSMs (low-occupancy kernels: they overlap
+    // with the other stream's work instead of serialising after the join)
+    const uint32_t Ww = p->sort_w.plan.W, Wh = p->sort_h.plan.W;
+    launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, p->sort_w.plan, s2);
+    launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 2, p->sort_w.plan, s2);
     HIP_TRY(hipEventRecord(p->ev_join, s2));
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
@@ -368,16 +375,16 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     mark(2);
     p->sort_h.run(p->h.p + p->sh.lo, s);
     mark(3);
-    // 6: MSM H (src/groth16.cpp:171-173)
+    // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
     launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1h.p, p->acc_key_h.p, p->acc_flag_h.p, s);
     mark(4);
-    HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
-    mark(5);
-    // bucket reduction -> window sums
-    const uint32_t Ww = p->sort_w.plan.W, Wh = p->sort_h.plan.W;
-    launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 3, p->sort_w.plan, s);
     launch_msm_reduce_g1(p->wsum_g1.p + 3 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(3, p->sort_w.plan), bH, 1, p->sort_h.plan, s);
-    launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, p->sort_w.plan, s);
+    // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w)
+    HIP_TRY(hipStreamWaitEvent(s, p->ev_sortw, 0));
+    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1h.p, p->acc_key_h.p, p->acc_flag_h.p, s);
+    launch_msm_reduce_g1(p->wsum_g1.p + 2 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(2, p->sort_w.plan), bC, 1, p->sort_w.plan, s);
+    mark(5);
+    HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
     mark(6);
     std::vector<uint8_t> w1((size_t)(3 * Ww + Wh) * sizeof(G1XYZZ)), w2((size_t)Ww * sizeof(G2XYZZ));
     HIP_TRY(hipMemcpyAsync(w1.data(), p->wsum_g1.p, w1.size(), hipMemcpyDeviceToHost, s));
@@ -393,8 +400,8 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
         p->timings[ZK_T_NTT] = ms[1];                // wall time on stream 1 (shares the GPU with stream2's MSMs)
         p->timings[ZK_T_DIGITS_SORT] = ms[2];        // sort(h)
         p->timings[ZK_T_MSM_H] = ms[3];              // whole MSM H accumulation on stream 1
-        p->timings[ZK_T_JOIN_WAIT] = ms[4];          // stream 1 waiting for stream2 (A,B1,C,B2)
-        p->timings[ZK_T_MSM_REDUCE] = ms[5];
+        p->timings[ZK_T_MSM_REDUCE] = ms[4];         // bucket reduction of MSM H (stream 1)
+        p->timings[ZK_T_JOIN_WAIT] = ms[5];          // stream 1 waiting for stream2 (A,B1,C,B2 + their reductions)
         p->timings[ZK_T_TOTAL_DEVICE] = ms[6];
         p->timings[ZK_T_G1_L1_KERNEL] = g1;          // k_msm_accum_l1<Fq>  of MSM A, tight events
         p->timings[ZK_T_G2_L1_KERNEL] = g2;          // k_msm_accum_l1<Fq2> of MSM B2, tight events
