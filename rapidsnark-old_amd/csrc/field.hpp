@@ -6,10 +6,11 @@
 // byte-identical to the reference's 4 x 64-bit FrElement/FqElement, so zkey/wtns
 // sections are used in place.
 //
-// CDNA4 has no 64x64 multiplier; the unit of work is v_mad_u64_u32 (32x32+64).  A row
-// of the CIOS product is a chain of MADs whose 64-bit addend carries the previous high
-// word, so no separate carry instructions are needed inside the row; the row is then
-// folded into the accumulator with one v_add_co/v_addc chain.
+// This 8x32-bit saturated form is the CONTAINER type of every HBM-resident element and the
+// arithmetic of the one-off / tool kernels (twiddle build, synthetic chains, zk_f*_mul_vec).
+// The hot kernels compute in 9x29-bit signed limbs instead (field29.hpp): on gfx950 a
+// v_addc_co_u32 costs as much as a v_mad_u64_u32, and this CIOS product needs ~250 of them
+// next to its 128 MADs (measured 87.8 G products/s vs 174 G for the 29-bit form).
 #pragma once
 #include <stdint.h>
 

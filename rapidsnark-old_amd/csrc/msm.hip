@@ -141,7 +141,8 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
 // LDS atomics only and writes counts[w][bucket][s]; one exclusive scan turns that into the
 // start of every (bucket, slice) run; the scatter workgroups rank their entries with LDS
 // atomics again.  No global atomics at all (the first version spent 83 % of its cycles
-// waiting on them), and the entry order inside a bucket is deterministic.
+// waiting on them).  The order of entries inside a bucket depends on LDS arbitration; the sum
+// does not.
 #define DIGIT_ZERO 0x7FFFu
 #define SORT_SLICES 16u
 #define SORT_THREADS 1024u

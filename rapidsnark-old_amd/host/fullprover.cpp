@@ -11,7 +11,6 @@
 #include <thread>
 
 #include "json_min.hpp"
-#include "wtns_utils.hpp"
 
 static const uint8_t kAltBn128r[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
                                        0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
@@ -40,14 +39,14 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
         if (memcmp(hdr->rPrime.data(), kAltBn128r, 32) != 0) throw std::invalid_argument("zkey curve not supported");
         const uint64_t sizes[6] = {zkey->getSectionSize(4), zkey->getSectionSize(5), zkey->getSectionSize(6),
                                    zkey->getSectionSize(7), zkey->getSectionSize(8), zkey->getSectionSize(9)};
-        provers[circuit] = Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
+        circuits[circuit].prover = Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
                                                hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
                                                zkey->getSectionData(5), zkey->getSectionData(6), zkey->getSectionData(7),
                                                zkey->getSectionData(8), zkey->getSectionData(9), sizes);
         // libzkhip copied everything it needs to the GPU: only the scalar header fields are kept
         // (the vk pointers into the mapping die with `zkey` and are never used again here)
         hdr->vk_alpha1 = hdr->vk_beta1 = hdr->vk_beta2 = hdr->vk_gamma2 = hdr->vk_delta1 = hdr->vk_delta2 = nullptr;
-        zkHeaders[circuit] = std::move(hdr);
+        circuits[circuit].header = std::move(hdr);
         std::cerr << "circuit: " << circuit << '\n';
     }
     status = ready;
@@ -55,20 +54,17 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
 
 void FullProver::startProve(std::string input, std::string circuit) {
     std::lock_guard<std::mutex> guard(mtx);
-    pendingInput = input;
-    pendingCircuit = circuit;
+    pending = Job{input, circuit};
     if (status == busy) canceled = true;   // reference: abort() here re-locks mtx and deadlocks (Q2)
     checkPending();
 }
 
 void FullProver::checkPending() {
     if (status == busy) return;
-    if (pendingInput.empty() || pendingCircuit.empty()) return;
+    if (pending.empty()) return;
     status = busy;
-    executingInput = pendingInput;
-    executingCircuit = pendingCircuit;
-    pendingInput.clear();
-    pendingCircuit.clear();
+    executing = pending;
+    pending.clear();
     errString.clear();
     canceled = false;
     proof = "null";
@@ -81,12 +77,12 @@ void FullProver::thread_calculateProve() {
         std::string input, circuit;
         {
             std::lock_guard<std::mutex> guard(mtx);
-            input = executingInput;
-            circuit = executingCircuit;
+            input = executing.input;
+            circuit = executing.circuit;
         }
         if (!JsonMin::isValid(input)) throw std::runtime_error("input is not valid JSON");
-        auto pit = provers.find(circuit);
-        if (pit == provers.end()) throw std::runtime_error("unknown circuit: " + circuit);
+        auto pit = circuits.find(circuit);
+        if (pit == circuits.end()) throw std::runtime_error("unknown circuit: " + circuit);
 
         // witness generation: the exact hand-off of fullprover.cpp:112-135 (same paths, same argv)
         {
@@ -108,7 +104,7 @@ void FullProver::thread_calculateProve() {
         auto wtns = BinFileUtils::openExisting(witnessFile, "wtns", 2);
         auto wtnsHeader = WtnsUtils::loadHeader(wtns.get());
         if (memcmp(wtnsHeader->prime.data(), kAltBn128r, 32) != 0) throw std::invalid_argument("different wtns curve");
-        const ZKeyUtils::Header *zh = zkHeaders[circuit].get();
+        const ZKeyUtils::Header *zh = pit->second.header.get();
         if (wtnsHeader->nVars != zh->nVars || wtns->getSectionSize(2) < (uint64_t)zh->nVars * 32)
             throw std::invalid_argument("witness does not match the zkey (nVars)");
         const uint8_t *wtnsData = static_cast<const uint8_t *>(wtns->getSectionData(2));
@@ -122,7 +118,7 @@ void FullProver::thread_calculateProve() {
         uint8_t r[32], s[32];
         bool fr = env_scalar("ZKHIP_FIXED_R", r), fs = env_scalar("ZKHIP_FIXED_S", s);
         std::string pr = "null";
-        if (!isCanceled()) pr = pit->second->prove(wtnsData, fr ? r : nullptr, fs ? s : nullptr)->toJson();   // HOT PATH (fullprover.cpp:155)
+        if (!isCanceled()) pr = pit->second.prover->prove(wtnsData, fr ? r : nullptr, fs ? s : nullptr)->toJson();   // HOT PATH (fullprover.cpp:155)
         {
             std::lock_guard<std::mutex> guard(mtx);
             pubData = pub;
@@ -144,7 +140,7 @@ void FullProver::calcFinished() {
     else if (!errString.empty()) status = failed;
     else status = success;
     canceled = false;
-    executingInput.clear();
+    executing.clear();
     checkPending();
 }
 

@@ -12,32 +12,40 @@
 #include <mutex>
 #include <string>
 
-#include "binfile_utils.hpp"
 #include "groth16.hpp"
-#include "zkey_utils.hpp"
+#include "zkfile.hpp"
 
 class FullProver {
+public:
+    FullProver(std::string zkeyFileNames[], int size);
+    void startProve(std::string input, std::string circuit);   // POST /input/:circuit
+    void abort();                                              // POST /cancel
+    std::string getStatus();                                   // the JSON document of GET /status
+
+private:
     enum Status { aborted = -2, busy = -1, failed = 0, success = 1, ready = 6 };
-    Status status = ready;
+
+    struct Circuit {
+        std::unique_ptr<Groth16::Prover> prover;
+        std::unique_ptr<ZKeyUtils::Header> header;   // scalar fields only (vk pointers are cleared after create)
+    };
+    struct Job {
+        std::string input, circuit;
+        bool empty() const { return input.empty() || circuit.empty(); }
+        void clear() { input.clear(); circuit.clear(); }
+    };
+
     std::mutex mtx;
-
-    std::string pendingInput, executingInput, pendingCircuit, executingCircuit;
-    std::map<std::string, std::unique_ptr<Groth16::Prover>> provers;
-    std::map<std::string, std::unique_ptr<ZKeyUtils::Header>> zkHeaders;
-
-    std::string proof;     // compact proof JSON
-    std::string pubData;   // compact JSON array of decimal strings
+    Status status = ready;
+    std::map<std::string, Circuit> circuits;   // keyed by zkey file stem
+    Job pending, executing;                    // one waiting slot: the latest request wins
+    std::string proof;                         // compact proof JSON of the last successful job
+    std::string pubData;                       // compact JSON array of decimal strings
     std::string errString;
     bool canceled = false;
 
     bool isCanceled();
     void calcFinished();
     void thread_calculateProve();
-    void checkPending();     // caller holds mtx
-
-public:
-    FullProver(std::string zkeyFileNames[], int size);
-    void startProve(std::string input, std::string circuit);
-    void abort();
-    std::string getStatus();   // the JSON document of GET /status
+    void checkPending();   // caller holds mtx
 };

@@ -1,20 +1,3 @@
-// WtnsUtils::loadHeader — reference src/wtns_utils.hpp:10-21, src/wtns_utils.cpp:12-25.
+// Compatibility include: the reference's wtns_utils.hpp surface lives in zkfile.hpp.
 #pragma once
-#include <array>
-#include <cstdint>
-#include <memory>
-
-#include "binfile_utils.hpp"
-
-namespace WtnsUtils {
-
-class Header {
-public:
-    uint32_t n8 = 0;
-    std::array<uint8_t, 32> prime{};
-    uint32_t nVars = 0;
-};
-
-std::unique_ptr<Header> loadHeader(BinFileUtils::BinFile *f);
-
-}   // namespace WtnsUtils
+#include "zkfile.hpp"
