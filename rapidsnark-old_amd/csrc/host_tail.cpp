@@ -8,6 +8,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <sys/random.h>
+#include <thread>
 #include <vector>
 
 namespace zk {
@@ -80,22 +81,42 @@ void HostTail::final_assembly(const uint8_t vk_alpha1[64], const uint8_t vk_beta
     G1P delta1 = G1P::from_affine(load<G1A>(vk_delta1));
     G2P delta2 = G2P::from_affine(load<G2A>(vk_delta2));
 
-    madd(pi_a, load<G1A>(vk_alpha1));                       // groth16.cpp:222
-    add(pi_a, scalar_mul(delta1, r));                       // :223-224
-    madd(pi_b, load<G2A>(vk_beta2));                        // :226
-    add(pi_b, scalar_mul(delta2, s));                       // :227-228
-    madd(pib1, load<G1A>(vk_beta1));                        // :230
-    add(pib1, scalar_mul(delta1, s));                       // :231-232
-    add(pi_c, pih);                                         // :234
-    add(pi_c, scalar_mul(pi_a, s));                         // :236-237
-    add(pi_c, scalar_mul(pib1, r));                         // :239-240
     // rs = toMontgomery(mul(r, s)) = r*s mod r_BN in standard form (:242-243)
     Fr64 fr, fs;
     memcpy(fr.v, r32, 32);
     memcpy(fs.v, s32, 32);
     Fr64 frs = Fr64::to_mont(Fr64::mul(fr, fs));
     memcpy(rs, frs.v, 32);
-    add(pi_c, neg(scalar_mul(delta1, rs)));                 // :245-246
+
+    // The six 256-bit scalar multiplications dominate this tail (~0.2 ms each in G1, ~0.55 ms in
+    // G2 on one core).  Four are independent of the MSM results, two more depend only on A / B1:
+    // two short waves of host threads instead of the reference's serial chain (:222-246).
+    G1P r_delta1, s_delta1, rs_delta1, s_A, r_B1;
+    G2P s_delta2;
+    {
+        std::thread t1([&] { r_delta1 = scalar_mul(delta1, r); });
+        std::thread t2([&] { s_delta1 = scalar_mul(delta1, s); });
+        std::thread t3([&] { rs_delta1 = scalar_mul(delta1, rs); });
+        s_delta2 = scalar_mul(delta2, s);
+        t1.join();
+        t2.join();
+        t3.join();
+    }
+    madd(pi_a, load<G1A>(vk_alpha1));                       // groth16.cpp:222
+    add(pi_a, r_delta1);                                    // :223-224
+    madd(pi_b, load<G2A>(vk_beta2));                        // :226
+    add(pi_b, s_delta2);                                    // :227-228
+    madd(pib1, load<G1A>(vk_beta1));                        // :230
+    add(pib1, s_delta1);                                    // :231-232
+    {
+        std::thread t1([&] { s_A = scalar_mul(pi_a, s); });
+        r_B1 = scalar_mul(pib1, r);
+        t1.join();
+    }
+    add(pi_c, pih);                                         // :234
+    add(pi_c, s_A);                                         // :236-237
+    add(pi_c, r_B1);                                        // :239-240
+    add(pi_c, neg(rs_delta1));                              // :245-246
     G1A A = to_affine(pi_a);                                // :249-251
     G2A B = to_affine(pi_b);
     G1A C = to_affine(pi_c);

@@ -89,11 +89,23 @@ def make_coefs(k: int, n_public: int, seed: int) -> np.ndarray:
     return img
 
 
-def make_witness(k: int, seed: int = 0) -> np.ndarray:
-    """nVars x 32 B standard form, w[0] = 1, others uniform in [0, r)."""
+def make_witness(k: int, seed: int = 0, kind: str = "uniform") -> np.ndarray:
+    """nVars x 32 B standard form, w[0] = 1.
+    kind = "uniform"   : every other entry uniform in [0, r)  — the worst case for the MSMs
+    kind = "realistic" : SURVEY §8d secondary line: 80 % of entries in {0, 1}, 15 % < 2^32, 5 % full-size
+                         (circom witnesses are dominated by booleans and small values)."""
     n = 1 << k
     rng = np.random.default_rng(0x5EED0000 + k + 1000003 * seed)
     w = random_fr_bytes(rng, n)
+    if kind == "realistic":
+        cls = rng.random(n)
+        small = cls < 0.80
+        mid = (cls >= 0.80) & (cls < 0.95)
+        w[small] = 0
+        w[small, 0] = rng.integers(0, 2, size=int(small.sum()), dtype=np.uint8)
+        w[mid, 4:] = 0
+    elif kind != "uniform":
+        raise ValueError("unknown witness kind %r" % kind)
     w[0] = 0
     w[0, 0] = 1
     return w.reshape(-1)
