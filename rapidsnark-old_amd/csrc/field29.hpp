@@ -312,6 +312,19 @@ struct Fp29 {
         to_words(r.v, canonical(x));
         return r;
     }
+    // a^(p-2) (Fermat); table building only.  Exponent bits come from the 29-bit limbs of p.
+    ZK_HD static Fq29 inv(const Fq29 &a) {
+        Fq29 result = one(), base = a;
+        for (int i = 0; i < 9 * 29; i++) {
+            int32_t limb = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) limb = (i / 29 == k) ? P[k] : limb;
+            if (i < 29) limb -= 2;                      // p - 2 (P[0] >= 2)
+            if ((limb >> (i % 29)) & 1) result = mul(result, base);
+            base = sqr(base);
+        }
+        return result;
+    }
     // value * 2^-261: leaves Montgomery form (standard-form result, e.g. MSM scalars)
     ZK_HD static Fq29 from_mont(const Fq29 &a) {
         Fq29 o = zero();

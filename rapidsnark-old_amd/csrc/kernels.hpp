@@ -52,21 +52,33 @@ void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, h
 // ---------------------------------------------------------------- msm.hip
 struct MsmPlan {
     uint32_t c;          // window bits
-    uint32_t W;          // windows = ceil(255 / c)
-    uint32_t nbuckets;   // per window = 2^(c-1)
+    uint32_t W;          // digit windows = ceil(256 / c)
+    uint32_t nbuckets;   // buckets per bucket set = 2^(c-1)
+    uint32_t sets;       // bucket sets: W normally, 1 with window-precomputed tables
+    uint32_t precomp;    // 1: tables hold 2^(c*j) P_i for j < W and every window shares one bucket set
 };
-MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits);
+MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp = false);
 
 // Digit recoding + counting sort of a scalar vector into bucket order (shared by every MSM over
-// that vector).  Buffer sizes (in elements) come from msm_sort_sizes().
+// that vector).  Buffer sizes (in elements) come from msm_sort_sizes(); unused ones are 0.
 struct MsmSortSizes {
     uint64_t digits_u16, counts_u32, starts_u32, offsets_u32, entries_u32;
+    uint64_t codes_u32, lo_u16, val_u32, bin_counts_u32, bin_starts_u32;    // window-precomputed mode only
+};
+struct MsmSortBufs {
+    uint32_t *offsets, *entries;          // outputs: bucket starts [sets*nbuckets + 1]; idx | sign<<31 in bucket order
+    uint16_t *digits;                     // plain mode: window-major 16-bit digit codes
+    uint32_t *counts, *starts;            // per-(bucket, slice) counts and their exclusive scan
+    uint32_t *codes, *val, *bin_counts, *bin_starts;   // precomp mode: 32-bit codes, bin-partitioned items
+    uint16_t *lo;
 };
 MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p);
 uint32_t msm_scan_extra_words(uint32_t total);
-// offsets[0..W*nbuckets] = start of every bucket's run in entries[]; entries = idx | sign<<31
-void launch_msm_sort(uint32_t *offsets, uint32_t *entries, uint16_t *digits, uint32_t *counts, uint32_t *starts,
-                     const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
+void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s);
+// table: W*n affine points, rows [0, n) already hold P_i (internal form); fills rows [n, W*n).
+// tmp: (W-1)*n XYZZ, pref: (W-1)*n field elements (scratch).
+void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s);
+void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s);
 // buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min.
 // max_entries: upper bound of offsets[total_buckets] (= n*W); ws_*: msm_accum_workspace_slots() slots.
 // ev (optional): two events recorded immediately before/after the level-1 kernel.

@@ -18,28 +18,36 @@
 // input is accepted like the reference's raw-byte interface.
 #include "kernels.hpp"
 #include "field29.hpp"
+#include <string.h>
 
 namespace zk {
 
 #define REDUCE_CHUNK 16u
 #define REDUCE_THREADS 256u
 
-MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits) {
+MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp) {
     MsmPlan p;
+    uint32_t lg = 0;
+    while ((1ull << (lg + 1)) <= n) lg++;
     uint32_t c = window_bits;
-    if (c == 0) {
-        uint32_t lg = 0;
-        while ((1ull << (lg + 1)) <= n) lg++;
-        c = lg > 6 ? lg - 6 : 2;     // ~128 points per bucket on random scalars
-        if (c > 16) c = 16;
+    if (precomp) {
+        // all windows share one bucket set (tables hold 2^(c*j) P): the reduction is paid once, so
+        // the window can grow until ~100 entries per bucket remain.  c = 17 buys nothing (W = 16).
+        if (c == 0) {
+            c = lg > 2 ? lg - 2 : 2;
+            if (c == 17) c = 18;
+        }
+        if (c > 20) c = 20;
+    } else {
+        if (c == 0) c = lg > 6 ? lg - 6 : 2;     // ~128 points per bucket on random scalars
+        if (c > 16) c = 16;                      // one window's histogram must fit one CU's LDS
     }
     if (c < 2) c = 2;
-    if (c > 20) c = 20;
     p.c = c;
-    if (c > 16) c = 16;             // the LDS histogram sort holds 2^(c-1) counters per workgroup
-    p.c = c;
-    p.W = (256 + c - 1) / c;        // W*c >= 256: the top digit is never negative (symmetric recoding)
+    p.W = (256 + c - 1) / c;        // W*c >= 256: the top digit is never negative
     p.nbuckets = 1u << (c - 1);
+    p.precomp = precomp ? 1u : 0u;
+    p.sets = precomp ? 1u : p.W;
     return p;
 }
 
@@ -147,7 +155,10 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
 #define SORT_SLICES 16u
 #define SORT_THREADS 1024u
 
-__global__ __launch_bounds__(256) void k_msm_digits(uint16_t *digits, const Fr *scalars, uint64_t n, MsmPlan p) {
+template <class CodeT>
+__global__ __launch_bounds__(256) void k_msm_digits(CodeT *digits, const Fr *scalars, uint64_t n, MsmPlan p) {
+    constexpr uint32_t SIGN = sizeof(CodeT) == 2 ? 0x8000u : 0x80000000u;
+    constexpr uint32_t ZERO = sizeof(CodeT) == 2 ? 0x7FFFu : 0x7FFFFFFFu;
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t c = p.c, W = p.W;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
@@ -169,8 +180,8 @@ __global__ __launch_bounds__(256) void k_msm_digits(uint16_t *digits, const Fr *
             const bool neg = d >= half;                  // digits in [-2^(c-1), 2^(c-1) - 1]
             carry = neg ? 1u : 0u;
             uint32_t mag = neg ? (1u << c) - d : d;      // 0 when raw = 2^c - 1 and carry = 1
-            uint32_t code = mag ? ((mag - 1u) | (neg ? 0x8000u : 0u)) : DIGIT_ZERO;
-            digits[(uint64_t)w * n + i] = (uint16_t)code;
+            uint32_t code = mag ? ((mag - 1u) | (neg ? SIGN : 0u)) : ZERO;
+            digits[(uint64_t)w * n + i] = (CodeT)code;
             w++;
         };
 #pragma unroll
@@ -225,6 +236,82 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_lds(uint32_t *entr
 __global__ __launch_bounds__(256) void k_msm_compact_offsets(uint32_t *offsets, const uint32_t *starts, uint32_t total) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k <= total) offsets[k] = starts[(uint64_t)k * SORT_SLICES];
+}
+
+// ---- window-precomputed mode: ONE bucket set of up to 2^19 buckets for all windows.  The key
+// space no longer fits an LDS histogram, so the flattened code array (window-major: its index
+// j*n + i IS the index of 2^(c*j) P_i in the precomputed table) is first partitioned by the high
+// bucket bits into <= 64 bins of 2^15 buckets, then every bin is counting-sorted exactly like a
+// window above.  32-bit codes: bit 31 sign, bits 0..30 = |d| - 1, 0x7FFFFFFF = zero digit.
+#define BIN_SHIFT 15u
+#define BIN_SPAN 16384u        // items per partition workgroup (1024 threads x 16)
+#define CODE32_ZERO 0x7FFFFFFFu
+
+__global__ __launch_bounds__(SORT_THREADS) void k_bin_count(uint32_t *bin_counts, const uint32_t *codes, uint64_t total, uint32_t nbins,
+                                                            uint32_t nblocks) {
+    __shared__ uint32_t hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * BIN_SPAN;
+    for (uint32_t k = threadIdx.x; k < BIN_SPAN; k += SORT_THREADS) {
+        uint64_t i = base + k;
+        if (i < total) {
+            uint32_t code = codes[i];
+            if ((code & 0x7FFFFFFFu) != CODE32_ZERO) atomicAdd(&hist[(code & 0x7FFFFFFFu) >> BIN_SHIFT], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nbins) bin_counts[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint32_t *val, const uint32_t *bin_starts, const uint32_t *codes,
+                                                              uint64_t total, uint32_t nbins, uint32_t nblocks) {
+    __shared__ uint32_t cursor[64];
+    if (threadIdx.x < nbins) cursor[threadIdx.x] = bin_starts[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * BIN_SPAN;
+    for (uint32_t k = threadIdx.x; k < BIN_SPAN; k += SORT_THREADS) {
+        uint64_t i = base + k;
+        if (i < total) {
+            uint32_t code = codes[i], mag = code & 0x7FFFFFFFu;
+            if (mag != CODE32_ZERO) {
+                uint32_t pos = atomicAdd(&cursor[mag >> BIN_SHIFT], 1u);
+                lo[pos] = (uint16_t)(mag & 0x7FFFu);
+                val[pos] = (uint32_t)i | (code & 0x80000000u);
+            }
+        }
+    }
+}
+
+// bin b occupies items [bin_starts[b*nblocks], bin_starts[(b+1)*nblocks]) (the scan array ends with the total)
+__global__ __launch_bounds__(SORT_THREADS) void k_bin_count_lds(uint32_t *counts, const uint16_t *lo, const uint32_t *bin_starts,
+                                                                uint32_t nblocks, uint32_t buckets_per_bin) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t b = blockIdx.x, slice = blockIdx.y;
+    for (uint32_t k = threadIdx.x; k < buckets_per_bin; k += SORT_THREADS) hist[k] = 0;
+    __syncthreads();
+    const uint64_t bs = bin_starts[(uint64_t)b * nblocks], be = bin_starts[(uint64_t)(b + 1) * nblocks];
+    const uint64_t len = be - bs, s0 = bs + len * slice / SORT_SLICES, s1 = bs + len * (slice + 1) / SORT_SLICES;
+    for (uint64_t i = s0 + threadIdx.x; i < s1; i += SORT_THREADS) atomicAdd(&hist[lo[i]], 1u);
+    __syncthreads();
+    uint32_t *out = counts + ((uint64_t)b << BIN_SHIFT) * SORT_SLICES + slice;
+    for (uint32_t k = threadIdx.x; k < buckets_per_bin; k += SORT_THREADS) out[(uint64_t)k * SORT_SLICES] = hist[k];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter_lds(uint32_t *entries, const uint32_t *starts, const uint16_t *lo,
+                                                                  const uint32_t *val, const uint32_t *bin_starts, uint32_t nblocks,
+                                                                  uint32_t buckets_per_bin) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t b = blockIdx.x, slice = blockIdx.y;
+    const uint32_t *in = starts + ((uint64_t)b << BIN_SHIFT) * SORT_SLICES + slice;
+    for (uint32_t k = threadIdx.x; k < buckets_per_bin; k += SORT_THREADS) cursor[k] = in[(uint64_t)k * SORT_SLICES];
+    __syncthreads();
+    const uint64_t bs = bin_starts[(uint64_t)b * nblocks], be = bin_starts[(uint64_t)(b + 1) * nblocks];
+    const uint64_t len = be - bs, s0 = bs + len * slice / SORT_SLICES, s1 = bs + len * (slice + 1) / SORT_SLICES;
+    for (uint64_t i = s0 + threadIdx.x; i < s1; i += SORT_THREADS) {
+        uint32_t pos = atomicAdd(&cursor[lo[i]], 1u);
+        entries[pos] = val[i];
+    }
 }
 
 // Exclusive scan in three coalesced launches: per-block (4096 elements) local scan + block
@@ -484,16 +571,20 @@ __global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, con
     store_xyzz(scratch + t, sum);
 }
 
-// One workgroup per (msm, window): strided serial sums, then an LDS tree.
+// Tree sum of `count` consecutive points per group, 2 inputs per lane + an LDS tree per workgroup:
+// grid (blocks_per_group, groups) -> one point per workgroup.  Launched repeatedly until one point
+// per (msm, window) is left; the last launch stores in the zkey's 2^256 Montgomery form.
+#define TREE_IN (2u * REDUCE_THREADS)
 template <class F>
-__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_final(XYZZ<F> *window_sums, const XYZZ<F> *scratch,
-                                                                     uint32_t chunks_per_window) {
+__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(XYZZ<F> *out, const XYZZ<F> *in, uint32_t count, uint32_t last) {
     extern __shared__ uint32_t lds_raw[];
     typedef REGF FR;
     XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);
-    const XYZZ<F> *X = scratch + (uint64_t)blockIdx.x * chunks_per_window;
+    const XYZZ<F> *X = in + (uint64_t)blockIdx.y * count;
+    const uint32_t i0 = blockIdx.x * TREE_IN + threadIdx.x, i1 = i0 + REDUCE_THREADS;
     XYZZ<FR> acc = XYZZ<FR>::inf();
-    for (uint32_t i = threadIdx.x; i < chunks_per_window; i += REDUCE_THREADS) add(acc, load_xyzz(X + i));
+    if (i0 < count) acc = load_xyzz(X + i0);
+    if (i1 < count) add(acc, load_xyzz(X + i1));
     lds[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = REDUCE_THREADS / 2; s > 0; s >>= 1) {
@@ -504,13 +595,24 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_final(XYZZ<F> *wi
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_xyzz_mont256(window_sums + blockIdx.x, acc);    // back to the zkey's 2^256 form
+    if (threadIdx.x == 0) {
+        XYZZ<F> *dst = out + (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (last) store_xyzz_mont256(dst, acc);    // back to the zkey's 2^256 form
+        else store_xyzz(dst, acc);
+    }
 }
 
 static inline uint32_t reduce_chunk_for(MsmPlan p) { return p.nbuckets < REDUCE_CHUNK ? p.nbuckets : REDUCE_CHUNK; }
 
+// scratch: chunk sums + the intermediate levels of the tree (a geometric tail)
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
-    return (uint64_t)n_msm * p.W * (p.nbuckets / reduce_chunk_for(p));
+    uint64_t groups = (uint64_t)n_msm * p.sets, cnt = p.nbuckets / reduce_chunk_for(p), total = 0;
+    for (;;) {
+        total += groups * cnt;
+        if (cnt == 1) break;
+        cnt = (cnt + TREE_IN - 1) / TREE_IN;
+    }
+    return total;
 }
 
 // exclusive scan of counts[0..total) -> out[0..total], out[total] = grand total;
@@ -524,39 +626,124 @@ static void launch_scan(uint32_t *out, const uint32_t *counts, uint32_t total, h
 }
 uint32_t msm_scan_extra_words(uint32_t total) { return (total + SCAN_ELEMS - 1) / SCAN_ELEMS; }
 
+static inline uint32_t plan_nbins(MsmPlan p) { return p.nbuckets > (1u << BIN_SHIFT) ? p.nbuckets >> BIN_SHIFT : 1u; }
+static inline uint32_t plan_bin_blocks(uint64_t n, MsmPlan p) { return (uint32_t)(((n ? n : 1) * p.W + BIN_SPAN - 1) / BIN_SPAN); }
+
 MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p) {
     MsmSortSizes z;
-    uint64_t tb = (uint64_t)p.W * p.nbuckets;
-    z.digits_u16 = (n ? n : 1) * p.W;
+    memset(&z, 0, sizeof z);
+    const uint64_t tb = (uint64_t)p.sets * p.nbuckets, items = (n ? n : 1) * p.W;
     z.counts_u32 = tb * SORT_SLICES;
     z.starts_u32 = tb * SORT_SLICES + 1 + msm_scan_extra_words((uint32_t)(tb * SORT_SLICES));
     z.offsets_u32 = tb + 1;
-    z.entries_u32 = (n ? n : 1) * p.W;
+    z.entries_u32 = items;
+    if (p.precomp) {
+        const uint64_t bb = (uint64_t)plan_nbins(p) * plan_bin_blocks(n, p);
+        z.codes_u32 = items;
+        z.lo_u16 = items;
+        z.val_u32 = items;
+        z.bin_counts_u32 = bb;
+        z.bin_starts_u32 = bb + 1 + msm_scan_extra_words((uint32_t)bb);
+    } else {
+        z.digits_u16 = items;
+    }
     return z;
 }
 
-// digits -> LDS histograms -> scan -> LDS-ranked scatter -> compact bucket offsets
-void launch_msm_sort(uint32_t *offsets, uint32_t *entries, uint16_t *digits, uint32_t *counts, uint32_t *starts,
-                     const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
-    const uint32_t tb = p.W * p.nbuckets;
-    const size_t lds = (size_t)p.nbuckets * 4;
+static void sort_lds_attr() {
     static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
-        (void)hipFuncSetAttribute((const void *)k_msm_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    if (n) {
-        uint64_t g = (n + 255) / 256;
-        if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(k_msm_digits, dim3((uint32_t)g), dim3(256), 0, s, digits, scalars, n, p);
-    }
-    hipLaunchKernelGGL(k_msm_count_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, counts, (const uint16_t *)digits, n, p);
-    launch_scan(starts, counts, tb * SORT_SLICES, s);
-    hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, entries, (const uint32_t *)starts,
-                       (const uint16_t *)digits, n, p);
-    hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, offsets, (const uint32_t *)starts, tb);
+    if (attr_set) return;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
+    (void)hipFuncSetAttribute((const void *)k_msm_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_bin_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_bin_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
 }
+
+// digits -> LDS histograms -> scan -> LDS-ranked scatter -> compact bucket offsets
+void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
+    const uint32_t tb = p.sets * p.nbuckets;
+    sort_lds_attr();
+    uint64_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (!p.precomp) {
+        const size_t lds = (size_t)p.nbuckets * 4;
+        if (n) hipLaunchKernelGGL(k_msm_digits<uint16_t>, dim3((uint32_t)g), dim3(256), 0, s, b.digits, scalars, n, p);
+        hipLaunchKernelGGL(k_msm_count_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.digits, n, p);
+        launch_scan(b.starts, b.counts, tb * SORT_SLICES, s);
+        hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
+                           (const uint16_t *)b.digits, n, p);
+    } else {
+        const uint32_t nbins = plan_nbins(p), nblocks = plan_bin_blocks(n, p);
+        const uint32_t bpb = p.nbuckets < (1u << BIN_SHIFT) ? p.nbuckets : (1u << BIN_SHIFT);
+        const uint64_t total = n * p.W;
+        const size_t lds = (size_t)bpb * 4;
+        if (n) hipLaunchKernelGGL(k_msm_digits<uint32_t>, dim3((uint32_t)g), dim3(256), 0, s, b.codes, scalars, n, p);
+        hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks);
+        launch_scan(b.bin_starts, b.bin_counts, nbins * nblocks, s);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.lo, b.val, (const uint32_t *)b.bin_starts,
+                           (const uint32_t *)b.codes, total, nbins, nblocks);
+        hipLaunchKernelGGL(k_bin_count_lds, dim3(nbins, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
+                           (const uint32_t *)b.bin_starts, nblocks, bpb);
+        launch_scan(b.starts, b.counts, tb * SORT_SLICES, s);
+        hipLaunchKernelGGL(k_bin_scatter_lds, dim3(nbins, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
+                           (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb);
+    }
+    hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb);
+}
+
+// ---------------------------------------------------------------- window pre-computation
+// T[j*n + i] = 2^(c*j) * P_i for j < W, affine, resident in HBM (x W table memory — what 288 GB
+// are for).  Every window then adds into the SAME bucket set, so the bucket reduction is paid
+// once and the window can grow to c = 20: 13 instead of 16 additions per point.
+template <class F>
+__global__ __launch_bounds__(128) void k_precomp_walk(XYZZ<F> *tmp, const Affine<F> *pts, uint64_t n, uint32_t c, uint32_t W) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef REGF FR;
+    XYZZ<FR> acc = XYZZ<FR>::from_affine(load_affine(pts + i));
+    for (uint32_t j = 1; j < W; j++) {
+        for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
+        store_xyzz(tmp + (uint64_t)(j - 1) * n + i, acc);
+    }
+}
+// XYZZ -> affine over segments of 64 points with one Fermat inversion per segment
+template <class F>
+__global__ __launch_bounds__(64) void k_precomp_normalize(Affine<F> *out, const XYZZ<F> *tmp, F *pref, uint64_t total) {
+    const uint64_t lo = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 64;
+    if (lo >= total) return;
+    const uint64_t hi = lo + 64 < total ? lo + 64 : total;
+    typedef REGF FR;
+    FR acc = FR::one();
+    for (uint64_t i = lo; i < hi; i++) {
+        Reg<F>::store(pref + i, acc);
+        FR t = FR::mul(Reg<F>::load(&tmp[i].zz), Reg<F>::load(&tmp[i].zzz));
+        if (!t.is_zero()) acc = FR::mul(acc, t);          // infinity (zz = 0): skipped
+    }
+    FR inv = FR::inv(acc);
+    for (uint64_t i = hi; i-- > lo;) {
+        FR zz = Reg<F>::load(&tmp[i].zz), zzz = Reg<F>::load(&tmp[i].zzz);
+        FR t = FR::mul(zz, zzz);
+        if (t.is_zero()) {
+            Reg<F>::store(&out[i].x, FR::zero());
+            Reg<F>::store(&out[i].y, FR::zero());
+            continue;
+        }
+        FR ii = FR::mul(inv, Reg<F>::load(pref + i));     // 1/(zz*zzz)
+        inv = FR::mul(inv, t);
+        Reg<F>::store(&out[i].x, FR::mul(Reg<F>::load(&tmp[i].x), FR::mul(ii, zzz)));   // X/ZZ
+        Reg<F>::store(&out[i].y, FR::mul(Reg<F>::load(&tmp[i].y), FR::mul(ii, zz)));    // Y/ZZZ
+    }
+}
+template <class F>
+static void precomp_table(Affine<F> *table, XYZZ<F> *tmp, F *pref, uint64_t n, MsmPlan p, hipStream_t s) {
+    if (!n || p.W < 2) return;
+    hipLaunchKernelGGL(k_precomp_walk<F>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, tmp, (const Affine<F> *)table, n, p.c, p.W);
+    const uint64_t total = (uint64_t)(p.W - 1) * n, segs = (total + 63) / 64;
+    hipLaunchKernelGGL(k_precomp_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, table + n, (const XYZZ<F> *)tmp, pref, total);
+}
+void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq>(table, tmp, pref, n, p, s); }
+void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq2>(table, tmp, pref, n, p, s); }
 
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
 static inline uint32_t accum_chunk_for(uint64_t max_entries) {
@@ -621,10 +808,21 @@ void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_
 template <class F>
 static void launch_reduce(XYZZ<F> *window_sums, XYZZ<F> *scratch, const XYZZ<F> *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     uint32_t chunk = reduce_chunk_for(p);
-    uint32_t cpw = p.nbuckets / chunk;
-    uint32_t total_chunks = n_msm * p.W * cpw;
+    uint32_t cnt = p.nbuckets / chunk;
+    const uint32_t groups = n_msm * p.sets;
+    uint32_t total_chunks = groups * cnt;
     hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks + 127) / 128), dim3(128), 0, s, scratch, buckets, p.nbuckets, chunk, total_chunks);
-    hipLaunchKernelGGL(k_msm_reduce_final<F>, dim3(n_msm * p.W), dim3(REDUCE_THREADS), REDUCE_THREADS * sizeof(XYZZ<typename Reg<F>::type>), s, window_sums, scratch, cpw);
+    const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename Reg<F>::type>);
+    XYZZ<F> *in = scratch;
+    for (;;) {
+        uint32_t blocks = (cnt + TREE_IN - 1) / TREE_IN;
+        bool last = blocks == 1;
+        XYZZ<F> *out = last ? window_sums : in + (uint64_t)groups * cnt;
+        hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(blocks, groups), dim3(REDUCE_THREADS), lds, s, out, (const XYZZ<F> *)in, cnt, last ? 1u : 0u);
+        if (last) break;
+        in = out;
+        cnt = blocks;
+    }
 }
 void launch_msm_reduce_g1(G1XYZZ *ws, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     launch_reduce<Fq>(ws, scratch, buckets, n_msm, p, s);

@@ -75,21 +75,28 @@ static Slice shard_slice(uint64_t n, uint32_t idx, uint32_t cnt) {
 struct SortBufs {
     MsmPlan plan;
     uint64_t n = 0;
-    DevBuf<uint16_t> digits;
-    DevBuf<uint32_t> counts, starts, offsets, entries;
-    uint32_t total_buckets() const { return plan.W * plan.nbuckets; }
-    void alloc(uint64_t n_, uint32_t window_bits) {
+    DevBuf<uint16_t> digits, lo;
+    DevBuf<uint32_t> counts, starts, offsets, entries, codes, val, bin_counts, bin_starts;
+    uint32_t total_buckets() const { return plan.sets * plan.nbuckets; }
+    uint64_t max_entries() const { return (n ? n : 1) * plan.W; }
+    void alloc(uint64_t n_, uint32_t window_bits, bool precomp = false) {
         n = n_;
-        plan = make_msm_plan(n ? n : 1, window_bits);
+        plan = make_msm_plan(n ? n : 1, window_bits, precomp);
         MsmSortSizes z = msm_sort_sizes(n, plan);
         digits.alloc(z.digits_u16);
+        lo.alloc(z.lo_u16);
         counts.alloc(z.counts_u32);
         starts.alloc(z.starts_u32);
         offsets.alloc(z.offsets_u32);
         entries.alloc(z.entries_u32);
+        codes.alloc(z.codes_u32);
+        val.alloc(z.val_u32);
+        bin_counts.alloc(z.bin_counts_u32);
+        bin_starts.alloc(z.bin_starts_u32);
     }
     void run(const Fr *scalars, hipStream_t s) {
-        launch_msm_sort(offsets.p, entries.p, digits.p, counts.p, starts.p, scalars, n, plan, s);
+        MsmSortBufs b{offsets.p, entries.p, digits.p, counts.p, starts.p, codes.p, val.p, bin_counts.p, bin_starts.p, lo.p};
+        launch_msm_sort(b, scalars, n, plan, s);
     }
 };
 
@@ -112,6 +119,7 @@ struct zk_prover {
     DevBuf<Fr> tw_fwd, tw_inv, tw_coset, tw_ninv;
     Slice sv, sh;              // this shard's slice of witness indices / domain indices
     uint32_t c_idx_min = 0;    // C-MSM: local witness index >= c_idx_min maps to pointsC[idx - c_idx_min]
+    bool precomp = false;      // window-precomputed tables (ZK_FLAG_PRECOMP): tables hold W rows of n points
     DevBuf<G1Affine> ptsA, ptsB1, ptsC, ptsH;
     DevBuf<G2Affine> ptsB2;
 
@@ -270,10 +278,15 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->sv = shard_slice(nV, p->shard_index, p->shard_count);
     p->sh = shard_slice(n, p->shard_index, p->shard_count);
     const uint64_t nv = p->sv.size(), nh = p->sh.size();
-    p->ptsA.alloc(nv ? nv : 1);
-    p->ptsB1.alloc(nv ? nv : 1);
-    p->ptsB2.alloc(nv ? nv : 1);
-    p->ptsH.alloc(nh ? nh : 1);
+    p->precomp = (p->flags & ZK_FLAG_PRECOMP) != 0;
+    p->sort_w.alloc(nv, wbits, p->precomp);
+    p->sort_h.alloc(nh, wbits, p->precomp);
+    // with window pre-computation a table holds W rows: row j = 2^(c*j) * P (msm.hip)
+    const uint64_t rows_w = p->precomp ? p->sort_w.plan.W : 1, rows_h = p->precomp ? p->sort_h.plan.W : 1;
+    p->ptsA.alloc((nv ? nv : 1) * rows_w);
+    p->ptsB1.alloc((nv ? nv : 1) * rows_w);
+    p->ptsB2.alloc((nv ? nv : 1) * rows_w);
+    p->ptsH.alloc((nh ? nh : 1) * rows_h);
     p->ptsA.upload((const uint8_t *)z->pointsA + p->sv.lo * 64, nv, s);
     p->ptsB1.upload((const uint8_t *)z->pointsB1 + p->sv.lo * 64, nv, s);
     p->ptsB2.upload((const uint8_t *)z->pointsB2 + p->sv.lo * 128, nv, s);
@@ -283,34 +296,57 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         uint64_t first = z->nPublic + 1;                 // first global witness index with a C point
         uint64_t lo = p->sv.lo > first ? p->sv.lo : first;
         uint64_t hi = p->sv.hi > lo ? p->sv.hi : lo;
-        p->c_idx_min = (uint32_t)(lo - p->sv.lo);
         uint64_t cnt = hi - lo;
-        p->ptsC.alloc(cnt ? cnt : 1);
-        p->ptsC.upload((const uint8_t *)z->pointsC + (lo - first) * 64, cnt, s);
-        launch_fq_to_internal((Fq *)p->ptsC.p, cnt * 2, s);
+        uint32_t skip = (uint32_t)(lo - p->sv.lo);       // leading witness rows of this shard without a C point
+        if (p->precomp) {
+            // same row indexing as A/B1 (entries address row j*nv + i): pad the public rows with infinity
+            p->ptsC.alloc((nv ? nv : 1) * rows_w);
+            HIP_TRY(hipMemsetAsync(p->ptsC.p, 0, (size_t)(nv ? nv : 1) * 64, s));
+            if (cnt) HIP_TRY(hipMemcpyAsync(p->ptsC.p + skip, (const uint8_t *)z->pointsC + (lo - first) * 64, cnt * 64, hipMemcpyHostToDevice, s));
+            p->c_idx_min = 0;
+            launch_fq_to_internal((Fq *)p->ptsC.p, nv * 2, s);
+        } else {
+            p->c_idx_min = skip;
+            p->ptsC.alloc(cnt ? cnt : 1);
+            p->ptsC.upload((const uint8_t *)z->pointsC + (lo - first) * 64, cnt, s);
+            launch_fq_to_internal((Fq *)p->ptsC.p, cnt * 2, s);
+        }
     }
     // MSM kernels work in the 2^261 Montgomery form (field29.hpp): convert the tables once
     launch_fq_to_internal((Fq *)p->ptsA.p, nv * 2, s);
     launch_fq_to_internal((Fq *)p->ptsB1.p, nv * 2, s);
     launch_fq_to_internal((Fq *)p->ptsB2.p, nv * 4, s);
     launch_fq_to_internal((Fq *)p->ptsH.p, nh * 2, s);
+    if (p->precomp) {
+        // one scratch area for the doubling walks, reused table after table (freed on return)
+        const uint64_t tw = (uint64_t)(p->sort_w.plan.W - 1) * (nv ? nv : 1), th = (uint64_t)(p->sort_h.plan.W - 1) * (nh ? nh : 1);
+        const uint64_t tmax = tw > th ? tw : th;
+        DevBuf<G2XYZZ> tmp;
+        DevBuf<Fq2> pref;
+        tmp.alloc(tmax ? tmax : 1);
+        pref.alloc(tmax ? tmax : 1);
+        launch_msm_precomp_g1(p->ptsA.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, p->sort_w.plan, s);
+        launch_msm_precomp_g1(p->ptsB1.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, p->sort_w.plan, s);
+        launch_msm_precomp_g1(p->ptsC.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, p->sort_w.plan, s);
+        launch_msm_precomp_g1(p->ptsH.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nh, p->sort_h.plan, s);
+        launch_msm_precomp_g2(p->ptsB2.p, tmp.p, pref.p, nv, p->sort_w.plan, s);
+        HIP_TRY(hipStreamSynchronize(s));
+    }
 
     // --- workspace
     p->wtns.alloc(nV);
     p->abc.alloc(3 * n);
     p->h.alloc(n);
-    p->sort_w.alloc(nv, wbits);
-    p->sort_h.alloc(nh, wbits);
     const uint64_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
     p->buckets_g1.alloc(3 * tbw + tbh);
     p->buckets_g2.alloc(tbw);
     {
         uint64_t s1 = msm_reduce_scratch_points(3, p->sort_w.plan) + msm_reduce_scratch_points(1, p->sort_h.plan);
         p->scratch_g1.alloc(s1);
-        p->wsum_g1.alloc(3 * p->sort_w.plan.W + p->sort_h.plan.W);
+        p->wsum_g1.alloc(3 * p->sort_w.plan.sets + p->sort_h.plan.sets);
         p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
-        p->wsum_g2.alloc(p->sort_w.plan.W);
-        uint64_t ew = (uint64_t)(nv ? nv : 1) * p->sort_w.plan.W, eh = (uint64_t)(nh ? nh : 1) * p->sort_h.plan.W;
+        p->wsum_g2.alloc(p->sort_w.plan.sets);
+        uint64_t ew = p->sort_w.max_entries(), eh = p->sort_h.max_entries();
         uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(ew > eh ? ew : eh);   // stream 1 runs H and C
         p->acc_ws_g1.alloc(slots);
         p->acc_ws_g2.alloc(slots);
@@ -340,7 +376,7 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
 
     const uint32_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
     G1XYZZ *bA = p->buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
-    const uint64_t ew = p->sort_w.n * p->sort_w.plan.W, eh = p->sort_h.n * p->sort_h.plan.W;
+    const uint64_t ew = p->sort_w.max_entries(), eh = p->sort_h.max_entries();
     hipStream_t s2 = p->stream2;
 
     mark(0);
@@ -356,7 +392,7 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2);
     // bucket reductions stay on the stream of their MSMs (low-occupancy kernels: they overlap
     // with the other stream's work instead of serialising after the join)
-    const uint32_t Ww = p->sort_w.plan.W, Wh = p->sort_h.plan.W;
+    const uint32_t Ww = p->sort_w.plan.sets, Wh = p->sort_h.plan.sets;     // window sums per MSM
     launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, p->sort_w.plan, s2);
     launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 2, p->sort_w.plan, s2);
     HIP_TRY(hipEventRecord(p->ev_join, s2));
@@ -622,14 +658,14 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     sb.run(sc.p, 0);
     DevBuf<XT> buckets, scratch, wsum, ws;
     DevBuf<uint32_t> wkey, wflag;
-    const uint64_t emax = n * sb.plan.W, slots = msm_accum_workspace_slots(emax);
+    const uint64_t emax = sb.max_entries(), slots = msm_accum_workspace_slots(emax);
     ws.alloc(slots);
     wkey.alloc(slots);
     wflag.alloc(slots);
     buckets.alloc(sb.total_buckets());
     scratch.alloc(msm_reduce_scratch_points(1, sb.plan));
-    wsum.alloc(sb.plan.W);
-    std::vector<uint8_t> w((size_t)sb.plan.W * sizeof(XT));
+    wsum.alloc(sb.plan.sets);
+    std::vector<uint8_t> w((size_t)sb.plan.sets * sizeof(XT));
     if constexpr (sizeof(AffT) == 64) {
         launch_msm_accum_g1((G1XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G1XYZZ *)ws.p, wkey.p, wflag.p, 0);
         launch_msm_reduce_g1((G1XYZZ *)wsum.p, (G1XYZZ *)scratch.p, (const G1XYZZ *)buckets.p, 1, sb.plan, 0);
@@ -638,8 +674,8 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
         launch_msm_reduce_g2((G2XYZZ *)wsum.p, (G2XYZZ *)scratch.p, (const G2XYZZ *)buckets.p, 1, sb.plan, 0);
     }
     HIP_TRY(hipMemcpy(w.data(), wsum.p, w.size(), hipMemcpyDeviceToHost));
-    if (g2) HostTail::combine_windows_g2(w.data(), sb.plan.W, sb.plan.c, out);
-    else HostTail::combine_windows_g1(w.data(), sb.plan.W, sb.plan.c, out);
+    if (g2) HostTail::combine_windows_g2(w.data(), sb.plan.sets, sb.plan.c, out);
+    else HostTail::combine_windows_g1(w.data(), sb.plan.sets, sb.plan.c, out);
 }
 
 template <class AffT, class XT, class FT>

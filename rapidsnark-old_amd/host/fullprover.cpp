@@ -42,7 +42,7 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
         circuits[circuit].prover = Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
                                                hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
                                                zkey->getSectionData(5), zkey->getSectionData(6), zkey->getSectionData(7),
-                                               zkey->getSectionData(8), zkey->getSectionData(9), sizes);
+                                               zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true);
         // libzkhip copied everything it needs to the GPU: only the scalar header fields are kept
         // (the vk pointers into the mapping die with `zkey` and are never used again here)
         hdr->vk_alpha1 = hdr->vk_beta1 = hdr->vk_beta2 = hdr->vk_gamma2 = hdr->vk_delta1 = hdr->vk_delta2 = nullptr;

@@ -6,6 +6,7 @@
 //     out << proof->toJson();                       // compact JSON, bytes of SURVEY §A.3
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -47,7 +48,7 @@ public:
 inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint32_t domainSize, uint64_t nCoefs,
                                           void *vk_alpha1, void *vk_beta1, void *vk_beta2, void *vk_delta1, void *vk_delta2,
                                           void *coefs, void *pointsA, void *pointsB1, void *pointsB2, void *pointsC,
-                                          void *pointsH, const uint64_t sectionBytes[6] = nullptr) {
+                                          void *pointsH, const uint64_t sectionBytes[6] = nullptr, bool precompDefault = false) {
     zk_zkey_view v{};
     v.nVars = nVars;
     v.nPublic = nPublic;
@@ -74,6 +75,11 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     }
     zk_opts o{};
     o.device = -1;
+    // ZKHIP_PRECOMP=1/0: window-precomputed tables (W x table memory, longer create, ~10 % faster
+    // proofs).  Default: off for the one-shot CLI, on for the server where create is amortised.
+    const char *pc = getenv("ZKHIP_PRECOMP");
+    if (pc ? (pc[0] == '1') : precompDefault) o.flags |= ZK_FLAG_PRECOMP;
+    if (const char *dev = getenv("ZKHIP_DEVICE")) o.device = atoi(dev);
     zk_prover *h = nullptr;
     if (zk_prover_create(&h, &v, &o) != 0) throw std::runtime_error(zk_last_error());
     return std::unique_ptr<Prover>(new Prover(h));

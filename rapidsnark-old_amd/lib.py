@@ -42,6 +42,7 @@ class zk_msm_sums(C.Structure):
 
 
 ZK_FLAG_TIMINGS = 1
+ZK_FLAG_PRECOMP = 2
 ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel"]
 
 # every symbol include/zkhip.h declares (tests check the library exports all of them)

@@ -13,7 +13,7 @@ BN254_R = 2188824287183927522224640574525727508854836440041603434369820418657580
 
 
 class Prover:
-    def __init__(self, zkey, device=-1, shard_index=0, shard_count=1, window_bits=0, timings=False):
+    def __init__(self, zkey, device=-1, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=False):
         """zkey: path or bytes of a snarkjs .zkey (version <= 1, main_prover.cpp:42)."""
         self._lib = L.load_library()
         f = open_existing(zkey, "zkey", 1)
@@ -36,7 +36,8 @@ class Prover:
             data = f.getSectionData(sec)                              # main_prover.cpp:67-72
             setattr(v, name, ptr(data))
             setattr(v, name + "_bytes", len(data))
-        o = L.zk_opts(device, shard_index, shard_count, window_bits, L.ZK_FLAG_TIMINGS if timings else 0)
+        o = L.zk_opts(device, shard_index, shard_count, window_bits,
+                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0))
         self._h = C.c_void_p()
         L.check(self._lib.zk_prover_create(C.byref(self._h), C.byref(v), C.byref(o)))
         self._keep = []     # host image may be released after create (include/zkhip.h)

@@ -31,7 +31,7 @@ def _gpu_workload(zk, k):
 def _prover(zk, wl, **kw):
     import bench
     return bench.ProverFromView(zk, wl, device=0, shard_index=kw.get("shard_index", 0), shard_count=kw.get("shard_count", 1),
-                                window_bits=kw.get("window_bits", 0), timings=False)
+                                window_bits=kw.get("window_bits", 0), timings=False, precomp=kw.get("precomp", False))
 
 
 @pytest.mark.parametrize("k", [10, 14, 16])
@@ -151,3 +151,16 @@ def test_realistic_witness_msm_parity(zk):
     p = _prover(zk, wl)
     wd = torch.from_numpy(w).to("cuda:0")
     assert p.prove_msm_dev(wd.data_ptr()) == co.prove_msm(co.ZkeyView(co.synth_workload(k)), w)
+
+
+@pytest.mark.parametrize("k,wbits", [(12, 0), (16, 0), (16, 17), (18, 20)])
+def test_precomp_mode_matches_plain_mode(zk, k, wbits):
+    """Window-precomputed tables (two-level sort, one bucket set, up to 2^19 buckets) vs the plain path."""
+    import torch
+    from rapidsnark_old_amd import synth
+    wl = _gpu_workload(zk, k)
+    for kind in ("uniform", "realistic"):
+        w = synth.make_witness(k, seed=2, kind=kind)
+        wd = torch.from_numpy(w).to("cuda:0")
+        base = _prover(zk, wl).prove_msm_dev(wd.data_ptr())
+        assert _prover(zk, wl, precomp=True, window_bits=wbits).prove_msm_dev(wd.data_ptr()) == base
