@@ -223,6 +223,22 @@ struct Fp29 {
         r.l[8] = (int32_t)acc;
         return r;
     }
+    // limb-wise add / sub WITHOUT the carry pass.  Bound bookkeeping (see curve29.hpp): a product
+    // tolerates |limb| <= 2^29+16 on both operands, or 2^30+32 on ONE of them; mul_add2 needs
+    // <= 2^29+16 on all four.  The difference of two values with non-negative limbs (e.g. two
+    // product outputs) already satisfies the tight bound.
+    ZK_HD static Fq29 add_nc(const Fq29 &a, const Fq29 &b) {
+        Fq29 t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.l[i] = a.l[i] + b.l[i];
+        return t;
+    }
+    ZK_HD static Fq29 sub_nc(const Fq29 &a, const Fq29 &b) {
+        Fq29 t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.l[i] = a.l[i] - b.l[i];
+        return t;
+    }
     // limb-wise negation / doubling WITHOUT the carry pass: valid as one operand of a product
     ZK_HD static Fq29 neg_lazy(const Fq29 &a) {
         Fq29 t;

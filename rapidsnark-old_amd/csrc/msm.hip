@@ -18,6 +18,7 @@
 // input is accepted like the reference's raw-byte interface.
 #include "kernels.hpp"
 #include "field29.hpp"
+#include "curve29.hpp"
 #include <string.h>
 
 namespace zk {
@@ -74,7 +75,6 @@ __device__ __forceinline__ void store_el(Fq2 *p, const Fq2 &r) {
 
 // Register representation of the MSM kernels: 9x29-bit signed limbs (field29.hpp).  HBM keeps
 // canonical 256-bit words of the SAME (2^261) Montgomery form; Reg<> converts at load/store.
-typedef Fp2T<Fq29> Fq2r;
 template <class FM> struct Reg;
 template <> struct Reg<Fq> {
     typedef Fq29 type;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
             if (e < hi) fetch(e);
             if (!skip) {
                 Affine<FR> P = to_reg_affine<F>(Pw);
-                if (ng) P.y = FR::neg(P.y);
-                madd(acc, P);
+                if (ng) negate_y(P);
+                madd(acc, P);          // curve29.hpp: bound-tracked specialisation
             }
             if (e == bend || e == hi) {              // the run of bucket b ends here (or is cut)
                 const bool ends = (e == bend);

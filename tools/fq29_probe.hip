@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <vector>
 #include <random>
-#include "../rapidsnark-old_amd/csrc/field29.hpp"
+#include "../rapidsnark-old_amd/csrc/curve29.hpp"
 using namespace zk;
 
 __global__ void k_check(const Fq *a, const Fq *b, int n, unsigned *bad) {
@@ -51,6 +51,28 @@ __global__ void k_check(const Fq *a, const Fq *b, int n, unsigned *bad) {
         Fq29 l2 = Fq29::mul_add2(D, D, S, Fq29::dbl_lazy(X));
         Fq29 r2 = Fq29::add(Fq29::sqr(D), Fq29::mul(S, Fq29::dbl(X)));
         if (!Fq29::sub(l2, r2).is_zero()) f |= 4096;
+    }
+    // 4c. specialised mixed add vs the generic template (same affine result): y^2 = x^3 + 3 points are
+    //     not needed for a formula-level identity check, any field elements will do
+    {
+        XYZZ<Fq29> g = XYZZ<Fq29>::inf(), h = XYZZ<Fq29>::inf();
+        Affine<Fq29> A1{X, Y}, A2{Fq29::mul(X, Y), Fq29::add(X, Y)}, A3{Fq29::sqr(Y), Fq29::sub(X, Y)};
+        for (int k = 0; k < 6; k++) {
+            Affine<Fq29> cur = k % 3 == 0 ? A1 : (k % 3 == 1 ? A2 : A3);
+            if (k & 1) { Affine<Fq29> n = cur; n.y = Fq29::neg(n.y); madd<Fq29>(g, n); negate_y(cur); madd(h, cur); }
+            else { madd<Fq29>(g, cur); madd(h, cur); }
+        }
+        if (!Fq29::sub(g.x, h.x).is_zero() || !Fq29::sub(g.y, h.y).is_zero() || !Fq29::sub(g.zz, h.zz).is_zero() ||
+            !Fq29::sub(g.zzz, h.zzz).is_zero()) f |= 8192;
+        XYZZ<Fq2r> g2 = XYZZ<Fq2r>::inf(), h2 = XYZZ<Fq2r>::inf();
+        Affine<Fq2r> B1{Fq2r{X, Y}, Fq2r{Fq29::mul(X, Y), Fq29::sqr(X)}}, B2{Fq2r{Fq29::sqr(Y), X}, Fq2r{Y, Fq29::sub(X, Y)}};
+        for (int k = 0; k < 5; k++) {
+            Affine<Fq2r> cur = (k & 1) ? B2 : B1;
+            if (k >= 2) { Affine<Fq2r> n = cur; n.y = Fq2r::neg(n.y); madd<Fq2r>(g2, n); negate_y(cur); madd(h2, cur); }
+            else { madd<Fq2r>(g2, cur); madd(h2, cur); }
+        }
+        if (!Fq2r::sub(g2.x, h2.x).is_zero() || !Fq2r::sub(g2.y, h2.y).is_zero() || !Fq2r::sub(g2.zz, h2.zz).is_zero() ||
+            !Fq2r::sub(g2.zzz, h2.zzz).is_zero()) f |= 16384;
     }
     // 5. load/store round trip of a canonical value
     if (!(Fq29::store(Fq29::load(x)) == x)) f |= 1024;
