@@ -74,23 +74,24 @@ ZK_HD void madd(XYZZ<Fq2r> &acc, const Affine<Fq2r> &p) {
         else acc = XYZZ<F>::inf();
         return;
     }
+    // ordered so that every temporary dies as early as possible (the kernel lives at the edge of
+    // the 256-VGPR file: fewer live values = fewer AGPR spill moves)
     F PP = f2_sqr_tight(P);
-    F PPP = f2_mul_tight(P, PP);
-    F Q = f2_mul_tight(acc.x, PP);
+    acc.zz = f2_mul_tight(acc.zz, PP);            // zz' (old zz dead)
+    F Q = f2_mul_tight(acc.x, PP);                // old x dead
+    F PPP = f2_mul_tight(P, PP);                  // P, PP dead
+    acc.zzz = f2_mul_tight(acc.zzz, PPP);         // zzz' (old zzz dead)
+    F T2 = f2_mul_tight(acc.y, PPP);              // old y dead
     F R2 = f2_sqr_tight(R);
-    F X3;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        X3.a.l[i] = R2.a.l[i] - PPP.a.l[i] - (Q.a.l[i] << 1);
-        X3.b.l[i] = R2.b.l[i] - PPP.b.l[i] - (Q.b.l[i] << 1);
+        acc.x.a.l[i] = R2.a.l[i] - PPP.a.l[i] - (Q.a.l[i] << 1);
+        acc.x.b.l[i] = R2.b.l[i] - PPP.b.l[i] - (Q.b.l[i] << 1);
     }
-    X3.a = B::carry(X3.a);
-    X3.b = B::carry(X3.b);
-    F D{B::sub_nc(Q.a, X3.a), B::sub_nc(Q.b, X3.b)};
-    F T1 = f2_mul_tight(R, D), T2 = f2_mul_tight(acc.y, PPP);
-    acc.zz = f2_mul_tight(acc.zz, PP);
-    acc.zzz = f2_mul_tight(acc.zzz, PPP);
-    acc.x = X3;
+    acc.x.a = B::carry(acc.x.a);                  // X3
+    acc.x.b = B::carry(acc.x.b);
+    F D{B::sub_nc(Q.a, acc.x.a), B::sub_nc(Q.b, acc.x.b)};
+    F T1 = f2_mul_tight(R, D);
     acc.y = F{B::sub(T1.a, T2.a), B::sub(T1.b, T2.b)};        // carried: keeps the next S2 - y tight
 }
 
