@@ -62,15 +62,14 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp = false);
 // Digit recoding + counting sort of a scalar vector into bucket order (shared by every MSM over
 // that vector).  Buffer sizes (in elements) come from msm_sort_sizes(); unused ones are 0.
 struct MsmSortSizes {
-    uint64_t digits_u16, counts_u32, starts_u32, offsets_u32, entries_u32;
-    uint64_t codes_u32, lo_u16, val_u32, bin_counts_u32, bin_starts_u32;    // window-precomputed mode only
+    uint64_t counts_u32, starts_u32, offsets_u32, entries_u32;
+    uint64_t codes_u32, lo_u16, val_u32, bin_counts_u32, bin_starts_u32;
 };
 struct MsmSortBufs {
     uint32_t *offsets, *entries;          // outputs: bucket starts [sets*nbuckets + 1]; idx | sign<<31 in bucket order
-    uint16_t *digits;                     // plain mode: window-major 16-bit digit codes
     uint32_t *counts, *starts;            // per-(bucket, slice) counts and their exclusive scan
-    uint32_t *codes, *val, *bin_counts, *bin_starts;   // precomp mode: 32-bit codes, bin-partitioned items
-    uint16_t *lo;
+    uint32_t *codes, *val, *bin_counts, *bin_starts;   // 32-bit digit codes (window-major); bin-partitioned items
+    uint16_t *lo;                         // low key bits of the bin-partitioned items
 };
 MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p);
 uint32_t msm_scan_extra_words(uint32_t total);

@@ -16,6 +16,7 @@
 //      30x faster on one CPU core than on one GPU lane.
 // Signed digits halve the bucket count; scalars are reduced mod r first so any 256-bit
 // input is accepted like the reference's raw-byte interface.
+#include <stdlib.h>
 #include "kernels.hpp"
 #include "field29.hpp"
 #include "curve29.hpp"
@@ -138,30 +139,29 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
 }
 
-// ---------------------------------------------------------------- digits + LDS counting sort
+// ---------------------------------------------------------------- digits + two-level LDS counting sort
 // Signed c-bit digits d in [-2^(c-1), 2^(c-1) - 1] (a window value >= 2^(c-1) becomes negative
-// and carries into the next window).  Digits are stored window-major as 16-bit codes:
-// bit 15 = sign, bits 0..14 = |d| - 1, 0x7FFF = zero digit (+2^(c-1) never occurs, so that
-// code is free even at c = 16).
+// and carries into the next window; +2^(c-1) never occurs).  Every non-zero digit becomes one
+// entry (table row | sign) keyed by its bucket; the sort brings the entries into bucket order.
 //
-// MI355X-specific: a whole window's histogram (2^(c-1) <= 32768 counters = 128 KiB) fits in
-// one CU's 160 KiB LDS.  Workgroup (window w, slice s) histograms its slice of the scalars with
-// LDS atomics only and writes counts[w][bucket][s]; one exclusive scan turns that into the
-// start of every (bucket, slice) run; the scatter workgroups rank their entries with LDS
-// atomics again.  No global atomics at all (the first version spent 83 % of its cycles
-// waiting on them).  The order of entries inside a bucket depends on LDS arbitration; the sum
-// does not.
-#define DIGIT_ZERO 0x7FFFu
-#define SORT_SLICES 16u
+// The key space (sets * 2^(c-1) buckets, 2^19 at 2^22) is sorted in two LDS-only levels:
+//   1. k_bin_count / k_bin_scatter partition the codes by their high key bits into <= 256 bins,
+//      staged through LDS so that the partitioned copy is written in coalesced runs;
+//   2. k_bin_count_lds / k_bin_scatter_lds counting-sort every bin (<= 2^15 buckets, normally
+//      2^11) with its histogram in LDS, `slices` workgroups per bin.
+// No global atomics at all (the first version spent 83 % of its cycles waiting on them).  The
+// order of entries inside a bucket depends on LDS arbitration; the sum does not.
+#define CODE32_ZERO 0x7FFFFFFFu
 #define SORT_THREADS 1024u
 
-template <class CodeT>
-__global__ __launch_bounds__(256) void k_msm_digits(CodeT *digits, const Fr *scalars, uint64_t n, MsmPlan p) {
-    constexpr uint32_t SIGN = sizeof(CodeT) == 2 ? 0x8000u : 0x80000000u;
-    constexpr uint32_t ZERO = sizeof(CodeT) == 2 ? 0x7FFFu : 0x7FFFFFFFu;
+// 32-bit codes, window-major: bit 31 = sign, bits 0..30 = bucket key, 0x7FFFFFFF = zero digit.
+// key = (|d| - 1) + w * nbuckets with per-window bucket sets, |d| - 1 with window-precomputed
+// tables (one shared set).
+__global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *scalars, uint64_t n, MsmPlan p) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t c = p.c, W = p.W;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    const uint32_t set_stride = p.precomp ? 0u : p.nbuckets;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
         Fr s = load_el(scalars + i);
         // any 256-bit value is < 6r: bring it below r (never loops for well-formed inputs)
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void k_msm_digits(CodeT *digits, const Fr *sca
             const bool neg = d >= half;                  // digits in [-2^(c-1), 2^(c-1) - 1]
             carry = neg ? 1u : 0u;
             uint32_t mag = neg ? (1u << c) - d : d;      // 0 when raw = 2^c - 1 and carry = 1
-            uint32_t code = mag ? ((mag - 1u) | (neg ? SIGN : 0u)) : ZERO;
-            digits[(uint64_t)w * n + i] = (CodeT)code;
+            uint32_t code = mag ? ((mag - 1u + w * set_stride) | (neg ? 0x80000000u : 0u)) : CODE32_ZERO;
+            digits[(uint64_t)w * n + i] = code;
             w++;
         };
 #pragma unroll
@@ -198,120 +198,159 @@ __global__ __launch_bounds__(256) void k_msm_digits(CodeT *digits, const Fr *sca
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_count_lds(uint32_t *counts, const uint16_t *digits, uint64_t n, MsmPlan p) {
-    extern __shared__ uint32_t hist[];
-    const uint32_t w = blockIdx.x, slice = blockIdx.y, nb = p.nbuckets;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
-    __syncthreads();
-    const uint64_t lo = n * slice / SORT_SLICES, hi = n * (slice + 1) / SORT_SLICES;
-    const uint16_t *d = digits + (uint64_t)w * n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        uint32_t code = d[i];
-        if (code != DIGIT_ZERO) atomicAdd(&hist[code & 0x7FFFu], 1u);
-    }
-    __syncthreads();
-    uint32_t *out = counts + (uint64_t)w * nb * SORT_SLICES + slice;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) out[(uint64_t)b * SORT_SLICES] = hist[b];
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_lds(uint32_t *entries, const uint32_t *starts, const uint16_t *digits,
-                                                                   uint64_t n, MsmPlan p) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t w = blockIdx.x, slice = blockIdx.y, nb = p.nbuckets;
-    const uint32_t *in = starts + (uint64_t)w * nb * SORT_SLICES + slice;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cursor[b] = in[(uint64_t)b * SORT_SLICES];
-    __syncthreads();
-    const uint64_t lo = n * slice / SORT_SLICES, hi = n * (slice + 1) / SORT_SLICES;
-    const uint16_t *d = digits + (uint64_t)w * n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        uint32_t code = d[i];
-        if (code != DIGIT_ZERO) {
-            uint32_t pos = atomicAdd(&cursor[code & 0x7FFFu], 1u);
-            entries[pos] = (uint32_t)i | ((code & 0x8000u) << 16);
-        }
-    }
-}
-
-// offsets[k] = start of bucket k = starts[k * SORT_SLICES]; offsets[total] = grand total
-__global__ __launch_bounds__(256) void k_msm_compact_offsets(uint32_t *offsets, const uint32_t *starts, uint32_t total) {
+// offsets[k] = start of bucket k = starts[k * slices]; offsets[total] = grand total
+__global__ __launch_bounds__(256) void k_msm_compact_offsets(uint32_t *offsets, const uint32_t *starts, uint32_t total, uint32_t slices) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k <= total) offsets[k] = starts[(uint64_t)k * SORT_SLICES];
+    if (k <= total) offsets[k] = starts[(uint64_t)k * slices];
 }
 
-// ---- window-precomputed mode: ONE bucket set of up to 2^19 buckets for all windows.  The key
-// space no longer fits an LDS histogram, so the flattened code array (window-major: its index
-// j*n + i IS the index of 2^(c*j) P_i in the precomputed table) is first partitioned by the high
-// bucket bits into <= 64 bins of 2^15 buckets, then every bin is counting-sorted exactly like a
-// window above.  32-bit codes: bit 31 sign, bits 0..30 = |d| - 1, 0x7FFFFFFF = zero digit.
-#define BIN_SHIFT 15u
-#define BIN_SPAN 16384u        // items per partition workgroup (1024 threads x 16)
-#define CODE32_ZERO 0x7FFFFFFFu
+// The bins are SMALL (2^11 buckets) on purpose: the second-level scatter writes 4-byte entries
+// at random inside its bin's output range, and only when the ranges being written at one time
+// fit the XCD's 4 MiB L2 do those writes leave the L2 as whole lines (measured at 2^22: 1.76 ms
+// with 2^15-bucket bins, 0.48 ms with 2^11).  The workgroups of one bin therefore run on one XCD
+// (block id -> XCD is round-robin) and each XCD walks its bins in order, `slices` workgroups at
+// a time.
+#define BIN_MAX 256u
 
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_count(uint32_t *bin_counts, const uint32_t *codes, uint64_t total, uint32_t nbins,
-                                                            uint32_t nblocks) {
-    __shared__ uint32_t hist[64];
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+                                                            uint32_t nblocks, uint32_t shift, uint32_t span) {
+    __shared__ uint32_t hist[BIN_MAX];
+    if (threadIdx.x < BIN_MAX) hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * BIN_SPAN;
-    for (uint32_t k = threadIdx.x; k < BIN_SPAN; k += SORT_THREADS) {
+    const uint64_t base = (uint64_t)blockIdx.x * span;
+    for (uint32_t k = threadIdx.x; k < span; k += SORT_THREADS) {
         uint64_t i = base + k;
         if (i < total) {
             uint32_t code = codes[i];
-            if ((code & 0x7FFFFFFFu) != CODE32_ZERO) atomicAdd(&hist[(code & 0x7FFFFFFFu) >> BIN_SHIFT], 1u);
+            if ((code & 0x7FFFFFFFu) != CODE32_ZERO) atomicAdd(&hist[(code & 0x7FFFFFFFu) >> shift], 1u);
         }
     }
     __syncthreads();
     if (threadIdx.x < nbins) bin_counts[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
+// First-level partition, staged through LDS: a workgroup ranks its `span` items per bin with LDS
+// atomics, lays them out bin-major in LDS, and writes them out so that consecutive lanes hit
+// consecutive addresses.  (Scattering straight from registers costs one cache-line request per
+// lane per store — 109 M line requests per sort at 2^22 — and was the larger half of the sort.)
+#define BIN_ITEMS 8u           // items per thread; span = BIN_ITEMS * SORT_THREADS
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint32_t *val, const uint32_t *bin_starts, const uint32_t *codes,
-                                                              uint64_t total, uint32_t nbins, uint32_t nblocks) {
-    __shared__ uint32_t cursor[64];
-    if (threadIdx.x < nbins) cursor[threadIdx.x] = bin_starts[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+                                                              uint64_t total, uint32_t nbins, uint32_t nblocks, uint32_t shift, uint32_t span, uint64_t n,
+                                                              uint32_t set_shift) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *cnt = smem;                         // [BIN_MAX] per-bin count, then LDS start
+    uint32_t *gdelta = smem + BIN_MAX;            // [BIN_MAX] global start - LDS start
+    uint32_t *st_dst = smem + 2 * BIN_MAX;        // [span]
+    uint32_t *st_val = st_dst + span;             // [span]
+    uint16_t *st_lo = (uint16_t *)(st_val + span);   // [span]
+    const uint32_t tid = threadIdx.x;
+    if (tid < BIN_MAX) cnt[tid] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * BIN_SPAN;
-    for (uint32_t k = threadIdx.x; k < BIN_SPAN; k += SORT_THREADS) {
-        uint64_t i = base + k;
-        if (i < total) {
-            uint32_t code = codes[i], mag = code & 0x7FFFFFFFu;
-            if (mag != CODE32_ZERO) {
-                uint32_t pos = atomicAdd(&cursor[mag >> BIN_SHIFT], 1u);
-                lo[pos] = (uint16_t)(mag & 0x7FFFu);
-                val[pos] = (uint32_t)i | (code & 0x80000000u);
-            }
+    const uint64_t base = (uint64_t)blockIdx.x * span;
+    const uint32_t lomask = (1u << shift) - 1u;
+    uint32_t code[BIN_ITEMS], rank[BIN_ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_ITEMS; k++) {
+        uint64_t i = base + (uint64_t)k * SORT_THREADS + tid;
+        code[k] = i < total ? codes[i] : CODE32_ZERO;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_ITEMS; k++) {
+        uint32_t mag = code[k] & 0x7FFFFFFFu;
+        rank[k] = mag != CODE32_ZERO ? atomicAdd(&cnt[mag >> shift], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the (<= 256) bin counts by wave 0: four bins per lane
+    if (tid < 64) {
+        uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+        uint32_t sum = c0 + c1 + c2 + c3, x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d);
+            if (tid >= (uint32_t)d) x += y;
+        }
+        uint32_t off = x - sum;
+        uint32_t o[4] = {off, off + c0, off + c0 + c1, off + c0 + c1 + c2};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t bin = 4 * tid + q;
+            cnt[bin] = o[q];
+            gdelta[bin] = bin < nbins ? bin_starts[(uint64_t)bin * nblocks + blockIdx.x] - o[q] : 0u;
+        }
+        if (tid == 63) smem[2 * BIN_MAX + 2 * span + span / 2] = x;      // total kept past st_lo
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_ITEMS; k++) {
+        uint32_t mag = code[k] & 0x7FFFFFFFu;
+        if (mag != CODE32_ZERO) {
+            uint32_t bin = mag >> shift, slot = cnt[bin] + rank[k];
+            // table row: the flattened index j*n + i itself with window-precomputed tables
+            // (set_shift = 32), the point index i otherwise (key >> set_shift = window j)
+            uint64_t i = base + (uint64_t)k * SORT_THREADS + tid - (uint64_t)(set_shift < 32 ? mag >> set_shift : 0u) * n;
+            st_dst[slot] = slot + gdelta[bin];
+            st_val[slot] = (uint32_t)i | (code[k] & 0x80000000u);
+            st_lo[slot] = (uint16_t)(mag & lomask);
         }
     }
+    __syncthreads();
+    const uint32_t kept = smem[2 * BIN_MAX + 2 * span + span / 2];
+    for (uint32_t sidx = tid; sidx < kept; sidx += SORT_THREADS) {
+        uint32_t d = st_dst[sidx];
+        val[d] = st_val[sidx];
+        lo[d] = st_lo[sidx];
+    }
+}
+
+// 1-D grid -> (bin, slice): XCD x (= block id mod 8) owns bins x, x+8, x+16, ... and walks them
+// in dispatch order, `slices` consecutive workgroups per bin.
+__device__ __forceinline__ bool bin_slice_of_block(uint32_t nbins, uint32_t slices, uint32_t &bin, uint32_t &slice) {
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    bin = (k / slices) * 8u + xcd;
+    slice = k % slices;
+    return bin < nbins;
 }
 
 // bin b occupies items [bin_starts[b*nblocks], bin_starts[(b+1)*nblocks]) (the scan array ends with the total)
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_count_lds(uint32_t *counts, const uint16_t *lo, const uint32_t *bin_starts,
-                                                                uint32_t nblocks, uint32_t buckets_per_bin) {
+                                                                uint32_t nblocks, uint32_t buckets_per_bin, uint32_t nbins, uint32_t slices,
+                                                                uint32_t total_buckets) {
     extern __shared__ uint32_t hist[];
-    const uint32_t b = blockIdx.x, slice = blockIdx.y;
-    for (uint32_t k = threadIdx.x; k < buckets_per_bin; k += SORT_THREADS) hist[k] = 0;
+    uint32_t b, slice;
+    if (!bin_slice_of_block(nbins, slices, b, slice)) return;
+    const uint32_t first = b * buckets_per_bin, nb = total_buckets - first < buckets_per_bin ? total_buckets - first : buckets_per_bin;
+    for (uint32_t k = threadIdx.x; k < nb; k += SORT_THREADS) hist[k] = 0;
     __syncthreads();
     const uint64_t bs = bin_starts[(uint64_t)b * nblocks], be = bin_starts[(uint64_t)(b + 1) * nblocks];
-    const uint64_t len = be - bs, s0 = bs + len * slice / SORT_SLICES, s1 = bs + len * (slice + 1) / SORT_SLICES;
+    const uint64_t len = be - bs, s0 = bs + len * slice / slices, s1 = bs + len * (slice + 1) / slices;
     for (uint64_t i = s0 + threadIdx.x; i < s1; i += SORT_THREADS) atomicAdd(&hist[lo[i]], 1u);
     __syncthreads();
-    uint32_t *out = counts + ((uint64_t)b << BIN_SHIFT) * SORT_SLICES + slice;
-    for (uint32_t k = threadIdx.x; k < buckets_per_bin; k += SORT_THREADS) out[(uint64_t)k * SORT_SLICES] = hist[k];
+    uint32_t *out = counts + (uint64_t)first * slices + slice;
+    for (uint32_t k = threadIdx.x; k < nb; k += SORT_THREADS) out[(uint64_t)k * slices] = hist[k];
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter_lds(uint32_t *entries, const uint32_t *starts, const uint16_t *lo,
                                                                   const uint32_t *val, const uint32_t *bin_starts, uint32_t nblocks,
-                                                                  uint32_t buckets_per_bin) {
+                                                                  uint32_t buckets_per_bin, uint32_t nbins, uint32_t slices, uint32_t total_buckets) {
     extern __shared__ uint32_t cursor[];
-    const uint32_t b = blockIdx.x, slice = blockIdx.y;
-    const uint32_t *in = starts + ((uint64_t)b << BIN_SHIFT) * SORT_SLICES + slice;
-    for (uint32_t k = threadIdx.x; k < buckets_per_bin; k += SORT_THREADS) cursor[k] = in[(uint64_t)k * SORT_SLICES];
+    uint32_t b, slice;
+    if (!bin_slice_of_block(nbins, slices, b, slice)) return;
+    const uint32_t first = b * buckets_per_bin, nb = total_buckets - first < buckets_per_bin ? total_buckets - first : buckets_per_bin;
+    const uint32_t *in = starts + (uint64_t)first * slices + slice;
+    for (uint32_t k = threadIdx.x; k < nb; k += SORT_THREADS) cursor[k] = in[(uint64_t)k * slices];
     __syncthreads();
     const uint64_t bs = bin_starts[(uint64_t)b * nblocks], be = bin_starts[(uint64_t)(b + 1) * nblocks];
-    const uint64_t len = be - bs, s0 = bs + len * slice / SORT_SLICES, s1 = bs + len * (slice + 1) / SORT_SLICES;
-    for (uint64_t i = s0 + threadIdx.x; i < s1; i += SORT_THREADS) {
-        uint32_t pos = atomicAdd(&cursor[lo[i]], 1u);
-        entries[pos] = val[i];
+    const uint64_t len = be - bs, s0 = bs + len * slice / slices, s1 = bs + len * (slice + 1) / slices;
+    uint64_t i = s0 + threadIdx.x;
+    for (; i + 3 * SORT_THREADS < s1; i += 4 * SORT_THREADS) {      // four independent loads in flight
+        uint32_t k0 = lo[i], k1 = lo[i + SORT_THREADS], k2 = lo[i + 2 * SORT_THREADS], k3 = lo[i + 3 * SORT_THREADS];
+        uint32_t v0 = val[i], v1 = val[i + SORT_THREADS], v2 = val[i + 2 * SORT_THREADS], v3 = val[i + 3 * SORT_THREADS];
+        entries[atomicAdd(&cursor[k0], 1u)] = v0;
+        entries[atomicAdd(&cursor[k1], 1u)] = v1;
+        entries[atomicAdd(&cursor[k2], 1u)] = v2;
+        entries[atomicAdd(&cursor[k3], 1u)] = v3;
     }
+    for (; i < s1; i += SORT_THREADS) entries[atomicAdd(&cursor[lo[i]], 1u)] = val[i];
 }
 
 // Exclusive scan in three coalesced launches: per-block (4096 elements) local scan + block
@@ -627,70 +666,69 @@ static void launch_scan(uint32_t *out, const uint32_t *counts, uint32_t total, h
 }
 uint32_t msm_scan_extra_words(uint32_t total) { return (total + SCAN_ELEMS - 1) / SCAN_ELEMS; }
 
-static inline uint32_t plan_nbins(MsmPlan p) { return p.nbuckets > (1u << BIN_SHIFT) ? p.nbuckets >> BIN_SHIFT : 1u; }
-static inline uint32_t plan_bin_blocks(uint64_t n, MsmPlan p) { return (uint32_t)(((n ? n : 1) * p.W + BIN_SPAN - 1) / BIN_SPAN); }
+// geometry of the two sort levels
+#define BIN_SHIFT 11u          // buckets per bin = 2^11 (see above)
+#define BIN_SLICES 32u         // second-level workgroups per bin
+static inline uint32_t plan_total_buckets(MsmPlan p) { return p.sets * p.nbuckets; }
+static inline uint32_t plan_bin_shift(MsmPlan p) {      // at most BIN_MAX bins; the low key bits travel as 16 bits
+    uint32_t sh = BIN_SHIFT;
+    while (((plan_total_buckets(p) + (1u << sh) - 1) >> sh) > BIN_MAX) sh++;
+    return sh;
+}
+static inline uint32_t plan_nbins(MsmPlan p) { uint32_t sh = plan_bin_shift(p); return (plan_total_buckets(p) + (1u << sh) - 1) >> sh; }
+static inline uint32_t bin_span() { return BIN_ITEMS * SORT_THREADS; }       // items per first-level workgroup
+static inline uint32_t plan_bin_blocks(uint64_t n, MsmPlan p) { return (uint32_t)(((n ? n : 1) * p.W + bin_span() - 1) / bin_span()); }
 
 MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p) {
     MsmSortSizes z;
     memset(&z, 0, sizeof z);
-    const uint64_t tb = (uint64_t)p.sets * p.nbuckets, items = (n ? n : 1) * p.W;
-    z.counts_u32 = tb * SORT_SLICES;
-    z.starts_u32 = tb * SORT_SLICES + 1 + msm_scan_extra_words((uint32_t)(tb * SORT_SLICES));
+    const uint64_t tb = plan_total_buckets(p), items = (n ? n : 1) * p.W;
+    const uint64_t bb = (uint64_t)plan_nbins(p) * plan_bin_blocks(n, p);
+    z.counts_u32 = tb * BIN_SLICES;
+    z.starts_u32 = tb * BIN_SLICES + 1 + msm_scan_extra_words((uint32_t)(tb * BIN_SLICES));
     z.offsets_u32 = tb + 1;
     z.entries_u32 = items;
-    if (p.precomp) {
-        const uint64_t bb = (uint64_t)plan_nbins(p) * plan_bin_blocks(n, p);
-        z.codes_u32 = items;
-        z.lo_u16 = items;
-        z.val_u32 = items;
-        z.bin_counts_u32 = bb;
-        z.bin_starts_u32 = bb + 1 + msm_scan_extra_words((uint32_t)bb);
-    } else {
-        z.digits_u16 = items;
-    }
+    z.codes_u32 = items;
+    z.lo_u16 = items;
+    z.val_u32 = items;
+    z.bin_counts_u32 = bb;
+    z.bin_starts_u32 = bb + 1 + msm_scan_extra_words((uint32_t)bb);
     return z;
 }
 
+static inline size_t bin_scatter_lds_bytes() { return (size_t)(2 * BIN_MAX + 2 * bin_span() + bin_span() / 2 + 1) * 4; }
 static void sort_lds_attr() {
     static bool attr_set = false;
     if (attr_set) return;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
-    (void)hipFuncSetAttribute((const void *)k_msm_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_bin_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_bin_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
 }
 
-// digits -> LDS histograms -> scan -> LDS-ranked scatter -> compact bucket offsets
+// digits -> bin partition -> per-bin LDS histograms -> scan -> LDS-ranked scatter -> compact bucket offsets
 void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPlan p, hipStream_t s) {
-    const uint32_t tb = p.sets * p.nbuckets;
+    const uint32_t tb = plan_total_buckets(p);
     sort_lds_attr();
     uint64_t g = (n + 255) / 256;
     if (g > 8192) g = 8192;
-    if (!p.precomp) {
-        const size_t lds = (size_t)p.nbuckets * 4;
-        if (n) hipLaunchKernelGGL(k_msm_digits<uint16_t>, dim3((uint32_t)g), dim3(256), 0, s, b.digits, scalars, n, p);
-        hipLaunchKernelGGL(k_msm_count_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.digits, n, p);
-        launch_scan(b.starts, b.counts, tb * SORT_SLICES, s);
-        hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.W, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
-                           (const uint16_t *)b.digits, n, p);
-    } else {
-        const uint32_t nbins = plan_nbins(p), nblocks = plan_bin_blocks(n, p);
-        const uint32_t bpb = p.nbuckets < (1u << BIN_SHIFT) ? p.nbuckets : (1u << BIN_SHIFT);
-        const uint64_t total = n * p.W;
-        const size_t lds = (size_t)bpb * 4;
-        if (n) hipLaunchKernelGGL(k_msm_digits<uint32_t>, dim3((uint32_t)g), dim3(256), 0, s, b.codes, scalars, n, p);
-        hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks);
-        launch_scan(b.bin_starts, b.bin_counts, nbins * nblocks, s);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.lo, b.val, (const uint32_t *)b.bin_starts,
-                           (const uint32_t *)b.codes, total, nbins, nblocks);
-        hipLaunchKernelGGL(k_bin_count_lds, dim3(nbins, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
-                           (const uint32_t *)b.bin_starts, nblocks, bpb);
-        launch_scan(b.starts, b.counts, tb * SORT_SLICES, s);
-        hipLaunchKernelGGL(k_bin_scatter_lds, dim3(nbins, SORT_SLICES), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
-                           (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb);
-    }
-    hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb);
+    const uint32_t sh = plan_bin_shift(p), nbins = plan_nbins(p), nblocks = plan_bin_blocks(n, p), slices = BIN_SLICES;
+    const uint32_t bpb = tb < (1u << sh) ? tb : (1u << sh);
+    const uint64_t total = n * p.W;
+    const size_t lds = (size_t)bpb * 4;
+    const uint32_t grid2 = ((nbins + 7u) / 8u) * 8u * slices;
+    const uint32_t set_shift = p.precomp ? 32u : p.c - 1u;
+    if (n) hipLaunchKernelGGL(k_msm_digits, dim3((uint32_t)g), dim3(256), 0, s, b.codes, scalars, n, p);
+    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span());
+    launch_scan(b.bin_starts, b.bin_counts, nbins * nblocks, s);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), bin_scatter_lds_bytes(), s, b.lo, b.val, (const uint32_t *)b.bin_starts,
+                       (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span(), n, set_shift);
+    hipLaunchKernelGGL(k_bin_count_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
+                       (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
+    launch_scan(b.starts, b.counts, tb * slices, s);
+    hipLaunchKernelGGL(k_bin_scatter_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
+                       (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
+    hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb, slices);
 }
 
 // ---------------------------------------------------------------- window pre-computation

@@ -75,7 +75,7 @@ static Slice shard_slice(uint64_t n, uint32_t idx, uint32_t cnt) {
 struct SortBufs {
     MsmPlan plan;
     uint64_t n = 0;
-    DevBuf<uint16_t> digits, lo;
+    DevBuf<uint16_t> lo;
     DevBuf<uint32_t> counts, starts, offsets, entries, codes, val, bin_counts, bin_starts;
     uint32_t total_buckets() const { return plan.sets * plan.nbuckets; }
     uint64_t max_entries() const { return (n ? n : 1) * plan.W; }
@@ -83,7 +83,6 @@ struct SortBufs {
         n = n_;
         plan = make_msm_plan(n ? n : 1, window_bits, precomp);
         MsmSortSizes z = msm_sort_sizes(n, plan);
-        digits.alloc(z.digits_u16);
         lo.alloc(z.lo_u16);
         counts.alloc(z.counts_u32);
         starts.alloc(z.starts_u32);
@@ -95,7 +94,7 @@ struct SortBufs {
         bin_starts.alloc(z.bin_starts_u32);
     }
     void run(const Fr *scalars, hipStream_t s) {
-        MsmSortBufs b{offsets.p, entries.p, digits.p, counts.p, starts.p, codes.p, val.p, bin_counts.p, bin_starts.p, lo.p};
+        MsmSortBufs b{offsets.p, entries.p, counts.p, starts.p, codes.p, val.p, bin_counts.p, bin_starts.p, lo.p};
         launch_msm_sort(b, scalars, n, plan, s);
     }
 };
@@ -143,7 +142,7 @@ struct zk_prover {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_sortw) (void)hipEventDestroy(ev_sortw);
-        if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -249,7 +248,10 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     memcpy(p->vk_delta2, z->vk_delta2, 128);
 
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+    // ZKHIP_SERIAL=1 (profiling aid): one stream, so that rocprofv3 kernel durations are not
+    // inflated by the other stream's kernels sharing the CUs.
+    if (getenv("ZKHIP_SERIAL")) p->stream2 = p->stream;
+    else HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_sortw, hipEventDisableTiming));
