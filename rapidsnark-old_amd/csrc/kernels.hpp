@@ -82,12 +82,20 @@ void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, 
 // max_entries: upper bound of offsets[total_buckets] (= n*W); ws_*: msm_accum_workspace_slots() slots.
 // ev (optional): two events recorded immediately before/after the level-1 kernel.
 uint64_t msm_accum_workspace_slots(uint64_t max_entries);
+// Optional follow-up stream of an accumulation: the level-1 kernel runs on `s`, the (small,
+// latency-bound) partial merges on `stream` once `l1_done` fires.
+struct AccumTail {
+    hipStream_t stream = nullptr;
+    hipEvent_t l1_done = nullptr;
+};
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         G1XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr);
+                         G1XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
+                         AccumTail tail = AccumTail());
 void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         G2XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr);
+                         G2XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
+                         AccumTail tail = AccumTail());
 // window_sums[m*W + w] = sum_k (k+1) * buckets[m][w][k]  for n_msm bucket arrays laid back to back;
 // scratch: n_msm * W * nbuckets/REDUCE_CHUNK points
 void launch_msm_reduce_g1(G1XYZZ *window_sums, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);

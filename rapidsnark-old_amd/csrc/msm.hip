@@ -809,7 +809,7 @@ uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
 template <class F>
 static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries, const Affine<F> *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev) {
+                         XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
     (void)hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s);
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
@@ -818,6 +818,11 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
                        points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
                        accum_chunk_for(max_entries ? max_entries : 1));
     if (ev) (void)hipEventRecord(ev[1], s);
+    if (tail.stream && tail.stream != s) {            // partial merges continue on the caller's follow-up stream
+        (void)hipEventRecord(tail.l1_done, s);
+        (void)hipStreamWaitEvent(tail.stream, tail.l1_done, 0);
+        s = tail.stream;
+    }
     if (lanes > 1)
         hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets,
                            (const XYZZ<F> *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
@@ -835,13 +840,13 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
 
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G1XYZZ *ws_part,
-                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev) {
-    launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev);
+                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
+    launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
 void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2XYZZ *ws_part,
-                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev) {
-    launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev);
+                         uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
+    launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
 
 template <class F>

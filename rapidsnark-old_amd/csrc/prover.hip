@@ -127,9 +127,13 @@ struct zk_prover {
     SortBufs sort_w, sort_h;
     DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
     DevBuf<G2XYZZ> buckets_g2;
-    DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1, acc_ws_g1h;   // ...h: the H chain runs concurrently on `stream`
+    // accumulation workspaces, one per MSM (their merges run asynchronously on stream3):
+    // 0 = A, 1 = B1, 2 = C, 3 = H (G1), 4 = B2 (G2)
+    DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1[4];
     DevBuf<G2XYZZ> scratch_g2, wsum_g2, acc_ws_g2;
-    DevBuf<uint32_t> acc_key, acc_flag, acc_key_h, acc_flag_h;
+    DevBuf<uint32_t> acc_key[5], acc_flag[5];
+    hipStream_t stream3 = nullptr, stream4 = nullptr;   // follow-up streams of stream2 / stream: partial merges + bucket reductions
+    hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
     hipEvent_t ev[14];
     bool have_events = false;
@@ -142,6 +146,10 @@ struct zk_prover {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_sortw) (void)hipEventDestroy(ev_sortw);
+        for (auto &e : ev_l1)
+            if (e) (void)hipEventDestroy(e);
+        if (stream3) (void)hipStreamDestroy(stream3);
+        if (stream4) (void)hipStreamDestroy(stream4);
         if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -252,6 +260,22 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     // inflated by the other stream's kernels sharing the CUs.
     if (getenv("ZKHIP_SERIAL")) p->stream2 = p->stream;
     else HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+    {
+        // Follow-up streams (highest priority) for the partial merges and bucket reductions: with
+        // long level-1 kernels these small kernels otherwise queue behind the next level-1 launch
+        // of their own stream and pile up after the last one (2^22: 44.0 -> 43.1 ms; at 2^20 the
+        // extra cross-stream hand-offs cost more than they save).  ZKHIP_TAIL=0/1 overrides.
+        const char *e = getenv("ZKHIP_TAIL");
+        bool follow = e ? atoi(e) != 0 : (uint64_t)z->domainSize * 13 >= (1ull << 25);
+        if (getenv("ZKHIP_SERIAL")) follow = false;
+        if (follow) {
+            int lo_pr = 0, hi_pr = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pr, &hi_pr));
+            HIP_TRY(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, hi_pr));
+            HIP_TRY(hipStreamCreateWithPriority(&p->stream4, hipStreamNonBlocking, hi_pr));
+        }
+        for (auto &ev1 : p->ev_l1) HIP_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_sortw, hipEventDisableTiming));
@@ -349,14 +373,14 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
         p->wsum_g2.alloc(p->sort_w.plan.sets);
         uint64_t ew = p->sort_w.max_entries(), eh = p->sort_h.max_entries();
-        uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(ew > eh ? ew : eh);   // stream 1 runs H and C
-        p->acc_ws_g1.alloc(slots);
-        p->acc_ws_g2.alloc(slots);
-        p->acc_key.alloc(slots);
-        p->acc_flag.alloc(slots);
-        p->acc_ws_g1h.alloc(slots_h);
-        p->acc_key_h.alloc(slots_h);
-        p->acc_flag_h.alloc(slots_h);
+        uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(eh);
+        for (int m = 0; m < 5; m++) {
+            const uint64_t sl = m == 3 ? slots_h : slots;
+            if (m < 4) p->acc_ws_g1[m].alloc(sl);
+            else p->acc_ws_g2.alloc(sl);
+            p->acc_key[m].alloc(sl);
+            p->acc_flag[m].alloc(sl);
+        }
     }
     for (auto &e : p->ev) HIP_TRY(hipEventCreate(&e));
     p->have_events = true;
@@ -389,14 +413,26 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     HIP_TRY(hipStreamWaitEvent(s2, p->ev_fork, 0));
     p->sort_w.run(d_wtns + p->sv.lo, s2);
     HIP_TRY(hipEventRecord(p->ev_sortw, s2));
-    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[10] : nullptr);
-    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2, tm ? &p->ev[8] : nullptr);
-    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1.p, p->acc_key.p, p->acc_flag.p, s2);
-    // bucket reductions stay on the stream of their MSMs (low-occupancy kernels: they overlap
-    // with the other stream's work instead of serialising after the join)
+    // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: with a
+    // third stream they neither delay the next level-1 kernel of their own stream nor pile up
+    // behind the last one
+    hipStream_t s3 = p->stream3, s4 = p->stream4;
+    auto tail_of = [&](int m) { AccumTail t; t.stream = (m == 2 || m == 3) ? s4 : s3; t.l1_done = p->ev_l1[m]; return t; };
+    auto after = [&](hipStream_t own) { return s4 ? s4 : own; };
     const uint32_t Ww = p->sort_w.plan.sets, Wh = p->sort_h.plan.sets;     // window sums per MSM
-    launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, p->sort_w.plan, s2);
-    launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 2, p->sort_w.plan, s2);
+    const MsmPlan pw = p->sort_w.plan;
+    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key[4].p, p->acc_flag[4].p, s2, tm ? &p->ev[10] : nullptr, tail_of(4));
+    if (s3) launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, pw, s3);
+    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1[0].p, p->acc_key[0].p, p->acc_flag[0].p, s2, tm ? &p->ev[8] : nullptr, tail_of(0));
+    if (s3) launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 1, pw, s3);
+    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1[1].p, p->acc_key[1].p, p->acc_flag[1].p, s2, nullptr, tail_of(1));
+    if (s3) {
+        launch_msm_reduce_g1(p->wsum_g1.p + Ww, p->scratch_g1.p + msm_reduce_scratch_points(1, pw), bB1, 1, pw, s3);
+    } else {
+        // bucket reductions stay on the stream of their MSMs
+        launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, pw, s2);
+        launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 2, pw, s2);
+    }
     HIP_TRY(hipEventRecord(p->ev_join, s2));
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
@@ -414,15 +450,21 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     p->sort_h.run(p->h.p + p->sh.lo, s);
     mark(3);
     // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
-    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1h.p, p->acc_key_h.p, p->acc_flag_h.p, s);
+    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1[3].p, p->acc_key[3].p, p->acc_flag[3].p, s, nullptr, tail_of(3));
     mark(4);
-    launch_msm_reduce_g1(p->wsum_g1.p + 3 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(3, p->sort_w.plan), bH, 1, p->sort_h.plan, s);
+    launch_msm_reduce_g1(p->wsum_g1.p + 3 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(3, pw), bH, 1, p->sort_h.plan, after(s));
     // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w)
     HIP_TRY(hipStreamWaitEvent(s, p->ev_sortw, 0));
-    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1h.p, p->acc_key_h.p, p->acc_flag_h.p, s);
-    launch_msm_reduce_g1(p->wsum_g1.p + 2 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(2, p->sort_w.plan), bC, 1, p->sort_w.plan, s);
+    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1[2].p, p->acc_key[2].p, p->acc_flag[2].p, s, nullptr, tail_of(2));
+    launch_msm_reduce_g1(p->wsum_g1.p + 2 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(2, pw), bC, 1, pw, after(s));
     mark(5);
     HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
+    if (s3) {                                   // everything queued on the follow-up streams
+        HIP_TRY(hipEventRecord(p->ev_l1[0], s3));       // (their level-1 events are consumed by now)
+        HIP_TRY(hipStreamWaitEvent(s, p->ev_l1[0], 0));
+        HIP_TRY(hipEventRecord(p->ev_l1[3], s4));
+        HIP_TRY(hipStreamWaitEvent(s, p->ev_l1[3], 0));
+    }
     mark(6);
     std::vector<uint8_t> w1((size_t)(3 * Ww + Wh) * sizeof(G1XYZZ)), w2((size_t)Ww * sizeof(G2XYZZ));
     HIP_TRY(hipMemcpyAsync(w1.data(), p->wsum_g1.p, w1.size(), hipMemcpyDeviceToHost, s));
