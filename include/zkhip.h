@@ -94,6 +94,17 @@ int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_
 /* Same with the witness already resident in device memory (HBM) on the prover's device. */
 int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out);
 
+/* Throughput mode: the same prove(), split so that consecutive proofs overlap.  The reference
+ * proves strictly one at a time (src/fullprover.cpp:96-97: one worker thread); on the GPU the
+ * latency-bound front of proof k+1 (digit sort, A.w/B.w, NTTs) hides under the tail of proof k
+ * (bucket reductions, D2H, host Horner + final assembly, src/groth16.cpp:219-251).
+ * zk_prove_dev_submit enqueues all device work of one proof and returns; at most TWO proofs may
+ * be in flight per prover.  zk_prove_collect blocks until the OLDEST submitted proof is complete
+ * and writes it.  d_wtns must stay valid (and unmodified) until its proof has been collected;
+ * r32/s32 are copied at submit (NULL = random, drawn at collect).  Not for sharded provers. */
+int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32);
+int zk_prove_collect(zk_prover *p, zk_proof *out);
+
 /* Multi-GPU split of prove(): steps 1-10 (src/groth16.cpp:52-204) on this prover's shard ... */
 int zk_prove_msm_dev(zk_prover *p, const void *d_wtns, zk_msm_sums *partial);
 int zk_prove_msm(zk_prover *p, const uint8_t *wtns, zk_msm_sums *partial);

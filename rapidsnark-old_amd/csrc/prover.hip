@@ -109,7 +109,6 @@ struct zk_prover {
     uint32_t shard_index = 0, shard_count = 1;
     uint8_t vk_alpha1[64], vk_beta1[64], vk_beta2[128], vk_delta1[64], vk_delta2[128];
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: witness-only MSM chain (A,B1,C,B2)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr;
     std::mutex mtx;
 
     // resident data
@@ -122,32 +121,49 @@ struct zk_prover {
     DevBuf<G1Affine> ptsA, ptsB1, ptsC, ptsH;
     DevBuf<G2Affine> ptsB2;
 
-    // per-proof workspace
+    // per-proof workspace used on `stream` only (in-order across consecutive proofs)
     DevBuf<Fr> wtns, abc, h;   // abc = a|b|c back to back
-    SortBufs sort_w, sort_h;
-    DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
-    DevBuf<G2XYZZ> buckets_g2;
-    // accumulation workspaces, one per MSM (their merges run asynchronously on stream3):
-    // 0 = A, 1 = B1, 2 = C, 3 = H (G1), 4 = B2 (G2)
-    DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1[4];
-    DevBuf<G2XYZZ> scratch_g2, wsum_g2, acc_ws_g2;
-    DevBuf<uint32_t> acc_key[5], acc_flag[5];
+    SortBufs sort_h;
+    // Everything a proof's witness-side streams and its asynchronous follow-up kernels touch lives
+    // in a ProofSlot; two slots let the front of proof k+1 (sort, SpMV, NTT: LDS/latency-bound)
+    // overlap the tail of proof k (merges, reductions, D2H, host Horner + assembly).
+    struct ProofSlot {
+        bool allocated = false, busy = false;
+        SortBufs sort_w;
+        DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
+        DevBuf<G2XYZZ> buckets_g2;
+        // accumulation workspaces, one per MSM: 0 = A, 1 = B1, 2 = C, 3 = H (G1), 4 = B2 (G2)
+        DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1[4];
+        DevBuf<G2XYZZ> scratch_g2, wsum_g2, acc_ws_g2;
+        DevBuf<uint32_t> acc_key[5], acc_flag[5];
+        hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_f3 = nullptr, ev_f4 = nullptr,
+                   ev_done = nullptr;
+        hipEvent_t ev[14];
+        bool have_events = false;
+        uint8_t *w1 = nullptr, *w2 = nullptr;      // pinned host copies of the window sums
+        size_t w1_bytes = 0, w2_bytes = 0;
+        uint8_t r32[32], s32[32];
+        bool have_r = false, have_s = false;
+        ~ProofSlot() {
+            for (auto &e : ev_l1) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_f3, ev_f4, ev_done}) if (e) (void)hipEventDestroy(e);
+            if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
+            if (w1) (void)hipHostFree(w1);
+            if (w2) (void)hipHostFree(w2);
+        }
+    };
+    ProofSlot slot[2];
+    uint32_t next_submit = 0, next_collect = 0, in_flight = 0;
+    uint32_t wbits = 0;
     hipStream_t stream3 = nullptr, stream4 = nullptr;   // follow-up streams of stream2 / stream: partial merges + bucket reductions
-    hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream_fin = nullptr;                   // joins a proof's streams and copies its window sums to the host
 
-    hipEvent_t ev[14];
-    bool have_events = false;
     double timings[ZK_T_COUNT] = {0};
     uint32_t accum_launches = 0;
 
     ~zk_prover() {
-        if (have_events)
-            for (auto &e : ev) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (ev_sortw) (void)hipEventDestroy(ev_sortw);
-        for (auto &e : ev_l1)
-            if (e) (void)hipEventDestroy(e);
+        if (stream_fin) (void)hipStreamDestroy(stream_fin);
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4);
         if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
@@ -218,6 +234,40 @@ void build_csr(const uint8_t *coefs /* after the u32 count */, uint64_t nCoefs, 
     }
 }
 
+// Device and pinned-host workspace of one in-flight proof.
+static void alloc_slot(zk_prover *p, int i) {
+    zk_prover::ProofSlot &q = p->slot[i];
+    if (q.allocated) return;
+    const uint64_t nv = p->sv.size();
+    q.sort_w.alloc(nv, p->wbits, p->precomp);
+    const MsmPlan pw = q.sort_w.plan, ph = p->sort_h.plan;
+    const uint64_t tbw = q.sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
+    q.buckets_g1.alloc(3 * tbw + tbh);
+    q.buckets_g2.alloc(tbw);
+    q.scratch_g1.alloc(msm_reduce_scratch_points(3, pw) + msm_reduce_scratch_points(1, ph));
+    q.wsum_g1.alloc(3 * pw.sets + ph.sets);
+    q.scratch_g2.alloc(msm_reduce_scratch_points(1, pw));
+    q.wsum_g2.alloc(pw.sets);
+    const uint64_t slots = msm_accum_workspace_slots(q.sort_w.max_entries()), slots_h = msm_accum_workspace_slots(p->sort_h.max_entries());
+    for (int m = 0; m < 5; m++) {
+        const uint64_t sl = m == 3 ? slots_h : slots;
+        if (m < 4) q.acc_ws_g1[m].alloc(sl);
+        else q.acc_ws_g2.alloc(sl);
+        q.acc_key[m].alloc(sl);
+        q.acc_flag[m].alloc(sl);
+    }
+    q.w1_bytes = (size_t)(3 * pw.sets + ph.sets) * sizeof(G1XYZZ);
+    q.w2_bytes = (size_t)pw.sets * sizeof(G2XYZZ);
+    HIP_TRY(hipHostMalloc((void **)&q.w1, q.w1_bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&q.w2, q.w2_bytes, hipHostMallocDefault));
+    for (auto &e : q.ev_l1) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t *e : {&q.ev_fork, &q.ev_join, &q.ev_sortw, &q.ev_main, &q.ev_f3, &q.ev_f4, &q.ev_done})
+        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (auto &e : q.ev) HIP_TRY(hipEventCreate(&e));
+    q.have_events = true;
+    q.allocated = true;
+}
+
 void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     if (!out || !z) throw std::invalid_argument("null argument");
     int ndev = 0;
@@ -274,11 +324,9 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             HIP_TRY(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, hi_pr));
             HIP_TRY(hipStreamCreateWithPriority(&p->stream4, hipStreamNonBlocking, hi_pr));
         }
-        for (auto &ev1 : p->ev_l1) HIP_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&p->ev_sortw, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream_fin, hipStreamNonBlocking));
+    p->wbits = wbits;
     hipStream_t s = p->stream;
 
     // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4)
@@ -305,10 +353,10 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->sh = shard_slice(n, p->shard_index, p->shard_count);
     const uint64_t nv = p->sv.size(), nh = p->sh.size();
     p->precomp = (p->flags & ZK_FLAG_PRECOMP) != 0;
-    p->sort_w.alloc(nv, wbits, p->precomp);
     p->sort_h.alloc(nh, wbits, p->precomp);
+    alloc_slot(p.get(), 0);
     // with window pre-computation a table holds W rows: row j = 2^(c*j) * P (msm.hip)
-    const uint64_t rows_w = p->precomp ? p->sort_w.plan.W : 1, rows_h = p->precomp ? p->sort_h.plan.W : 1;
+    const uint64_t rows_w = p->precomp ? p->slot[0].sort_w.plan.W : 1, rows_h = p->precomp ? p->sort_h.plan.W : 1;
     p->ptsA.alloc((nv ? nv : 1) * rows_w);
     p->ptsB1.alloc((nv ? nv : 1) * rows_w);
     p->ptsB2.alloc((nv ? nv : 1) * rows_w);
@@ -345,95 +393,85 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     launch_fq_to_internal((Fq *)p->ptsH.p, nh * 2, s);
     if (p->precomp) {
         // one scratch area for the doubling walks, reused table after table (freed on return)
-        const uint64_t tw = (uint64_t)(p->sort_w.plan.W - 1) * (nv ? nv : 1), th = (uint64_t)(p->sort_h.plan.W - 1) * (nh ? nh : 1);
+        const MsmPlan plan_w = p->slot[0].sort_w.plan;
+        const uint64_t tw = (uint64_t)(plan_w.W - 1) * (nv ? nv : 1), th = (uint64_t)(p->sort_h.plan.W - 1) * (nh ? nh : 1);
         const uint64_t tmax = tw > th ? tw : th;
         DevBuf<G2XYZZ> tmp;
         DevBuf<Fq2> pref;
         tmp.alloc(tmax ? tmax : 1);
         pref.alloc(tmax ? tmax : 1);
-        launch_msm_precomp_g1(p->ptsA.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, p->sort_w.plan, s);
-        launch_msm_precomp_g1(p->ptsB1.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, p->sort_w.plan, s);
-        launch_msm_precomp_g1(p->ptsC.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, p->sort_w.plan, s);
+        launch_msm_precomp_g1(p->ptsA.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, plan_w, s);
+        launch_msm_precomp_g1(p->ptsB1.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, plan_w, s);
+        launch_msm_precomp_g1(p->ptsC.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nv, plan_w, s);
         launch_msm_precomp_g1(p->ptsH.p, (G1XYZZ *)tmp.p, (Fq *)pref.p, nh, p->sort_h.plan, s);
-        launch_msm_precomp_g2(p->ptsB2.p, tmp.p, pref.p, nv, p->sort_w.plan, s);
+        launch_msm_precomp_g2(p->ptsB2.p, tmp.p, pref.p, nv, plan_w, s);
         HIP_TRY(hipStreamSynchronize(s));
     }
 
-    // --- workspace
+    // --- workspace (slot 0 was allocated above; slot 1 appears with the first overlapped submit)
     p->wtns.alloc(nV);
     p->abc.alloc(3 * n);
     p->h.alloc(n);
-    const uint64_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
-    p->buckets_g1.alloc(3 * tbw + tbh);
-    p->buckets_g2.alloc(tbw);
-    {
-        uint64_t s1 = msm_reduce_scratch_points(3, p->sort_w.plan) + msm_reduce_scratch_points(1, p->sort_h.plan);
-        p->scratch_g1.alloc(s1);
-        p->wsum_g1.alloc(3 * p->sort_w.plan.sets + p->sort_h.plan.sets);
-        p->scratch_g2.alloc(msm_reduce_scratch_points(1, p->sort_w.plan));
-        p->wsum_g2.alloc(p->sort_w.plan.sets);
-        uint64_t ew = p->sort_w.max_entries(), eh = p->sort_h.max_entries();
-        uint64_t slots = msm_accum_workspace_slots(ew), slots_h = msm_accum_workspace_slots(eh);
-        for (int m = 0; m < 5; m++) {
-            const uint64_t sl = m == 3 ? slots_h : slots;
-            if (m < 4) p->acc_ws_g1[m].alloc(sl);
-            else p->acc_ws_g2.alloc(sl);
-            p->acc_key[m].alloc(sl);
-            p->acc_flag[m].alloc(sl);
-        }
-    }
-    for (auto &e : p->ev) HIP_TRY(hipEventCreate(&e));
-    p->have_events = true;
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
     *out = p.release();
 }
 
-// Steps 1-10 of prove() on the device + Horner on the host.  d_wtns: device pointer, nVars x 32 B.
-void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
-    std::lock_guard<std::mutex> lk(p->mtx);
+// Steps 1-10 of prove() (src/groth16.cpp:52-204), device part: everything is enqueued, nothing waits.
+// d_wtns: device pointer, nVars x 32 B, must stay valid until the proof is collected.
+// Caller holds p->mtx.
+static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, const uint8_t *s32) {
+    if (p->in_flight >= 2) throw std::invalid_argument("two proofs already in flight: collect one first");
     DeviceGuard g(p->device);
+    const int si = (int)(p->next_submit & 1u);
+    alloc_slot(p, si);
+    zk_prover::ProofSlot &q = p->slot[si];
+    q.have_r = r32 != nullptr;
+    q.have_s = s32 != nullptr;
+    if (r32) memcpy(q.r32, r32, 32);
+    if (s32) memcpy(q.s32, s32, 32);
+
     hipStream_t s = p->stream;
     const uint64_t n = p->domainSize;
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
     auto mark = [&](int i) {
-        if (tm) HIP_TRY(hipEventRecord(p->ev[i], s));
+        if (tm) HIP_TRY(hipEventRecord(q.ev[i], s));
     };
     Fr *a = p->abc.p, *b = p->abc.p + n, *c = p->abc.p + 2 * n;
 
-    const uint32_t tbw = p->sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
-    G1XYZZ *bA = p->buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
-    const uint64_t ew = p->sort_w.max_entries(), eh = p->sort_h.max_entries();
+    const uint32_t tbw = q.sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
+    G1XYZZ *bA = q.buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
+    const uint64_t ew = q.sort_w.max_entries(), eh = p->sort_h.max_entries();
     hipStream_t s2 = p->stream2;
 
     mark(0);
     // ---- stream2: work that depends on the witness only (the reference runs it AFTER the FFT
     // chain, src/groth16.cpp:180-204; it is independent of it): sort(w) once, then MSM B2, A, B1
     // over the shared bucket order.  MSM C joins stream 1 behind MSM H to balance the streams.
-    HIP_TRY(hipEventRecord(p->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(s2, p->ev_fork, 0));
-    p->sort_w.run(d_wtns + p->sv.lo, s2);
-    HIP_TRY(hipEventRecord(p->ev_sortw, s2));
-    // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: with a
-    // third stream they neither delay the next level-1 kernel of their own stream nor pile up
+    HIP_TRY(hipEventRecord(q.ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(s2, q.ev_fork, 0));
+    q.sort_w.run(d_wtns + p->sv.lo, s2);
+    HIP_TRY(hipEventRecord(q.ev_sortw, s2));
+    // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: on their
+    // own streams they neither delay the next level-1 kernel of their MSM's stream nor pile up
     // behind the last one
     hipStream_t s3 = p->stream3, s4 = p->stream4;
-    auto tail_of = [&](int m) { AccumTail t; t.stream = (m == 2 || m == 3) ? s4 : s3; t.l1_done = p->ev_l1[m]; return t; };
+    auto tail_of = [&](int m) { AccumTail t; t.stream = (m == 2 || m == 3) ? s4 : s3; t.l1_done = q.ev_l1[m]; return t; };
     auto after = [&](hipStream_t own) { return s4 ? s4 : own; };
-    const uint32_t Ww = p->sort_w.plan.sets, Wh = p->sort_h.plan.sets;     // window sums per MSM
-    const MsmPlan pw = p->sort_w.plan;
-    launch_msm_accum_g2(p->buckets_g2.p, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, p->acc_ws_g2.p, p->acc_key[4].p, p->acc_flag[4].p, s2, tm ? &p->ev[10] : nullptr, tail_of(4));
-    if (s3) launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, pw, s3);
-    launch_msm_accum_g1(bA, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, p->acc_ws_g1[0].p, p->acc_key[0].p, p->acc_flag[0].p, s2, tm ? &p->ev[8] : nullptr, tail_of(0));
-    if (s3) launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 1, pw, s3);
-    launch_msm_accum_g1(bB1, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, p->acc_ws_g1[1].p, p->acc_key[1].p, p->acc_flag[1].p, s2, nullptr, tail_of(1));
+    const uint32_t Ww = q.sort_w.plan.sets;     // window sums per MSM
+    const MsmPlan pw = q.sort_w.plan;
+    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4].p, q.acc_flag[4].p, s2, tm ? &q.ev[10] : nullptr, tail_of(4));
+    if (s3) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s3);
+    launch_msm_accum_g1(bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0].p, q.acc_key[0].p, q.acc_flag[0].p, s2, tm ? &q.ev[8] : nullptr, tail_of(0));
+    if (s3) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, bA, 1, pw, s3);
+    launch_msm_accum_g1(bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1].p, q.acc_key[1].p, q.acc_flag[1].p, s2, nullptr, tail_of(1));
     if (s3) {
-        launch_msm_reduce_g1(p->wsum_g1.p + Ww, p->scratch_g1.p + msm_reduce_scratch_points(1, pw), bB1, 1, pw, s3);
+        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), bB1, 1, pw, s3);
     } else {
         // bucket reductions stay on the stream of their MSMs
-        launch_msm_reduce_g2(p->wsum_g2.p, p->scratch_g2.p, p->buckets_g2.p, 1, pw, s2);
-        launch_msm_reduce_g1(p->wsum_g1.p, p->scratch_g1.p, bA, 2, pw, s2);
+        launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
+        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, bA, 2, pw, s2);
     }
-    HIP_TRY(hipEventRecord(p->ev_join, s2));
+    HIP_TRY(hipEventRecord(q.ev_join, s2));
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
     // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96)
@@ -450,55 +488,86 @@ void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
     p->sort_h.run(p->h.p + p->sh.lo, s);
     mark(3);
     // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
-    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, p->acc_ws_g1[3].p, p->acc_key[3].p, p->acc_flag[3].p, s, nullptr, tail_of(3));
+    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, q.acc_ws_g1[3].p, q.acc_key[3].p, q.acc_flag[3].p, s, nullptr, tail_of(3));
     mark(4);
-    launch_msm_reduce_g1(p->wsum_g1.p + 3 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(3, pw), bH, 1, p->sort_h.plan, after(s));
+    launch_msm_reduce_g1(q.wsum_g1.p + 3 * Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, pw), bH, 1, p->sort_h.plan, after(s));
     // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w)
-    HIP_TRY(hipStreamWaitEvent(s, p->ev_sortw, 0));
-    launch_msm_accum_g1(bC, p->sort_w.offsets.p, p->sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, p->acc_ws_g1[2].p, p->acc_key[2].p, p->acc_flag[2].p, s, nullptr, tail_of(2));
-    launch_msm_reduce_g1(p->wsum_g1.p + 2 * Ww, p->scratch_g1.p + msm_reduce_scratch_points(2, pw), bC, 1, pw, after(s));
+    HIP_TRY(hipStreamWaitEvent(s, q.ev_sortw, 0));
+    launch_msm_accum_g1(bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, q.acc_ws_g1[2].p, q.acc_key[2].p, q.acc_flag[2].p, s, nullptr, tail_of(2));
+    launch_msm_reduce_g1(q.wsum_g1.p + 2 * Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, pw), bC, 1, pw, after(s));
     mark(5);
-    HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
-    if (s3) {                                   // everything queued on the follow-up streams
-        HIP_TRY(hipEventRecord(p->ev_l1[0], s3));       // (their level-1 events are consumed by now)
-        HIP_TRY(hipStreamWaitEvent(s, p->ev_l1[0], 0));
-        HIP_TRY(hipEventRecord(p->ev_l1[3], s4));
-        HIP_TRY(hipStreamWaitEvent(s, p->ev_l1[3], 0));
+    HIP_TRY(hipEventRecord(q.ev_main, s));
+
+    // ---- join on the finishing stream (the main streams go straight on to the next proof):
+    // window sums -> pinned host memory
+    hipStream_t sf = p->stream_fin;
+    HIP_TRY(hipStreamWaitEvent(sf, q.ev_main, 0));
+    HIP_TRY(hipStreamWaitEvent(sf, q.ev_join, 0));
+    if (s3) {
+        HIP_TRY(hipEventRecord(q.ev_f3, s3));
+        HIP_TRY(hipStreamWaitEvent(sf, q.ev_f3, 0));
+        HIP_TRY(hipEventRecord(q.ev_f4, s4));
+        HIP_TRY(hipStreamWaitEvent(sf, q.ev_f4, 0));
     }
-    mark(6);
-    std::vector<uint8_t> w1((size_t)(3 * Ww + Wh) * sizeof(G1XYZZ)), w2((size_t)Ww * sizeof(G2XYZZ));
-    HIP_TRY(hipMemcpyAsync(w1.data(), p->wsum_g1.p, w1.size(), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(w2.data(), p->wsum_g2.p, w2.size(), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (tm) HIP_TRY(hipEventRecord(q.ev[6], sf));
+    HIP_TRY(hipMemcpyAsync(q.w1, q.wsum_g1.p, q.w1_bytes, hipMemcpyDeviceToHost, sf));
+    HIP_TRY(hipMemcpyAsync(q.w2, q.wsum_g2.p, q.w2_bytes, hipMemcpyDeviceToHost, sf));
+    HIP_TRY(hipEventRecord(q.ev_done, sf));
+    q.busy = true;
+    p->next_submit++;
+    p->in_flight++;
+}
+
+// Waits for the oldest proof in flight, then the host part: Horner over the window sums
+// (c doublings per window).  Caller holds p->mtx.
+static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out) {
+    if (!p->in_flight) throw std::invalid_argument("no proof in flight");
+    DeviceGuard g(p->device);
+    zk_prover::ProofSlot &q = p->slot[p->next_collect & 1u];
+    p->next_collect++;
+    p->in_flight--;
+    q.busy = false;
+    HIP_TRY(hipEventSynchronize(q.ev_done));
+    const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
     if (tm) {
         float ms[7], g1 = 0, g2 = 0;
-        for (int i = 0; i < 6; i++) HIP_TRY(hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&ms[6], p->ev[0], p->ev[6]));
-        HIP_TRY(hipEventElapsedTime(&g1, p->ev[8], p->ev[9]));
-        HIP_TRY(hipEventElapsedTime(&g2, p->ev[10], p->ev[11]));
+        for (int i = 0; i < 5; i++) HIP_TRY(hipEventElapsedTime(&ms[i], q.ev[i], q.ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms[5], q.ev[5], q.ev[6]));
+        HIP_TRY(hipEventElapsedTime(&ms[6], q.ev[0], q.ev[6]));
+        HIP_TRY(hipEventElapsedTime(&g1, q.ev[8], q.ev[9]));
+        HIP_TRY(hipEventElapsedTime(&g2, q.ev[10], q.ev[11]));
         p->timings[ZK_T_SPMV] = ms[0];
         p->timings[ZK_T_NTT] = ms[1];                // wall time on stream 1 (shares the GPU with stream2's MSMs)
         p->timings[ZK_T_DIGITS_SORT] = ms[2];        // sort(h)
-        p->timings[ZK_T_MSM_H] = ms[3];              // whole MSM H accumulation on stream 1
-        p->timings[ZK_T_MSM_REDUCE] = ms[4];         // bucket reduction of MSM H (stream 1)
-        p->timings[ZK_T_JOIN_WAIT] = ms[5];          // stream 1 waiting for stream2 (A,B1,C,B2 + their reductions)
+        p->timings[ZK_T_MSM_H] = ms[3];              // level-1 accumulation of MSM H on stream 1
+        p->timings[ZK_T_MSM_REDUCE] = ms[4];         // MSM C on stream 1 (+ the follow-ups of H and C without follow-up streams)
+        p->timings[ZK_T_JOIN_WAIT] = ms[5];          // end of stream 1's work -> every stream of the proof joined
         p->timings[ZK_T_TOTAL_DEVICE] = ms[6];
         p->timings[ZK_T_G1_L1_KERNEL] = g1;          // k_msm_accum_l1<Fq>  of MSM A, tight events
         p->timings[ZK_T_G2_L1_KERNEL] = g2;          // k_msm_accum_l1<Fq2> of MSM B2, tight events
     }
-    // host Horner over windows (c doublings per window)
-    const uint32_t cw = p->sort_w.plan.c, ch = p->sort_h.plan.c;
+    const uint32_t Ww = q.sort_w.plan.sets, Wh = p->sort_h.plan.sets;
+    const uint32_t cw = q.sort_w.plan.c, ch = p->sort_h.plan.c;
     const size_t P1 = sizeof(G1XYZZ);
+    const uint8_t *w1 = q.w1, *w2 = q.w2;
     // five independent serial chains (W*c doublings each): one host thread per chain
-    std::thread t1([&] { HostTail::combine_windows_g1(w1.data(), Ww, cw, out->pi_a); });
-    std::thread t2([&] { HostTail::combine_windows_g1(w1.data() + (size_t)Ww * P1, Ww, cw, out->pib1); });
-    std::thread t3([&] { HostTail::combine_windows_g1(w1.data() + (size_t)2 * Ww * P1, Ww, cw, out->pi_c); });
-    std::thread t4([&] { HostTail::combine_windows_g1(w1.data() + (size_t)3 * Ww * P1, Wh, ch, out->pih); });
-    HostTail::combine_windows_g2(w2.data(), Ww, cw, out->pi_b);
+    std::thread t1([&] { HostTail::combine_windows_g1(w1, Ww, cw, out->pi_a); });
+    std::thread t2([&] { HostTail::combine_windows_g1(w1 + (size_t)Ww * P1, Ww, cw, out->pib1); });
+    std::thread t3([&] { HostTail::combine_windows_g1(w1 + (size_t)2 * Ww * P1, Ww, cw, out->pi_c); });
+    std::thread t4([&] { HostTail::combine_windows_g1(w1 + (size_t)3 * Ww * P1, Wh, ch, out->pih); });
+    HostTail::combine_windows_g2(w2, Ww, cw, out->pi_b);
     t1.join();
     t2.join();
     t3.join();
     t4.join();
+    return q;
+}
+
+void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
+    std::lock_guard<std::mutex> lk(p->mtx);
+    if (p->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
+    submit_locked(p, d_wtns, nullptr, nullptr);
+    collect_sums_locked(p, out);
 }
 
 void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
@@ -576,6 +645,33 @@ int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_
         zk_msm_sums sums;
         prove_msm(p, stage_witness(p, wtns), &sums);
         prove_finish(p, &sums, 1, r32, s32, out);
+    });
+}
+
+int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32) {
+    return guarded([&] {
+        if (!p || !d_wtns) throw std::invalid_argument("null argument");
+        if (p->shard_count != 1) throw std::invalid_argument("zk_prove_dev_submit on a sharded prover");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        submit_locked(p, (const Fr *)d_wtns, r32, s32);
+    });
+}
+
+int zk_prove_collect(zk_prover *p, zk_proof *out) {
+    return guarded([&] {
+        if (!p || !out) throw std::invalid_argument("null argument");
+        zk_msm_sums sums;
+        uint8_t r32[32], s32[32];
+        bool have_r, have_s;
+        {
+            std::lock_guard<std::mutex> lk(p->mtx);
+            zk_prover::ProofSlot &q = collect_sums_locked(p, &sums);
+            have_r = q.have_r;
+            have_s = q.have_s;
+            memcpy(r32, q.r32, 32);
+            memcpy(s32, q.s32, 32);
+        }
+        prove_finish(p, &sums, 1, have_r ? r32 : nullptr, have_s ? s32 : nullptr, out);
     });
 }
 

@@ -87,6 +87,18 @@ class Prover:
         L.check(self._lib.zk_prove_dev(self._h, C.c_void_p(d_wtns_ptr), rp, sp, C.byref(out)))
         return bytes(out)
 
+    def submit_dev(self, d_wtns_ptr, r=None, s=None):
+        """Throughput mode (zk_prove_dev_submit): enqueue one proof; at most two in flight.  The device
+        witness must stay valid until the matching collect()."""
+        (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
+        L.check(self._lib.zk_prove_dev_submit(self._h, C.c_void_p(d_wtns_ptr), rp, sp))
+
+    def collect(self):
+        """-> proof bytes of the OLDEST submitted proof (zk_prove_collect)."""
+        out = L.zk_proof()
+        L.check(self._lib.zk_prove_collect(self._h, C.byref(out)))
+        return bytes(out)
+
     def prove_msm(self, wtns):
         a = self._wtns_values(wtns)
         out = L.zk_msm_sums()
