@@ -439,7 +439,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 #define FLAG_STARTS 1u
 #define FLAG_ENDS 2u
 
-// G1 fits 128 VGPRs (4 waves/SIMD) when asked to; G2 needs the whole file (1 wave/SIMD)
+// Occupancy is what the compiler picks: G1 132 VGPRs (3 waves/SIMD), G2 256 + 53 AGPRs (1 wave/SIMD).
+// Forcing 4 G1 waves (128 VGPRs, 20 B scratch) or 2 G2 waves (256 VGPRs, 256 B scratch) was measured
+// slower for the whole proof.
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                       const Affine<F> *points, uint32_t idx_min, uint32_t idx_sub,
