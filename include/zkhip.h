@@ -101,9 +101,12 @@ int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uin
  * zk_prove_dev_submit enqueues all device work of one proof and returns; at most TWO proofs may
  * be in flight per prover.  zk_prove_collect blocks until the OLDEST submitted proof is complete
  * and writes it.  d_wtns must stay valid (and unmodified) until its proof has been collected;
- * r32/s32 are copied at submit (NULL = random, drawn at collect).  Not for sharded provers. */
+ * r32/s32 are copied at submit (NULL = random, drawn at collect).  On a sharded prover the pair is
+ * zk_prove_dev_submit (r32/s32 ignored) + zk_prove_msm_collect, which hands back this shard's
+ * partial sums for zk_prove_finish. */
 int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32);
 int zk_prove_collect(zk_prover *p, zk_proof *out);
+int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);
 
 /* Multi-GPU split of prove(): steps 1-10 (src/groth16.cpp:52-204) on this prover's shard ... */
 int zk_prove_msm_dev(zk_prover *p, const void *d_wtns, zk_msm_sums *partial);

@@ -651,15 +651,23 @@ int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_
 int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32) {
     return guarded([&] {
         if (!p || !d_wtns) throw std::invalid_argument("null argument");
-        if (p->shard_count != 1) throw std::invalid_argument("zk_prove_dev_submit on a sharded prover");
         std::lock_guard<std::mutex> lk(p->mtx);
         submit_locked(p, (const Fr *)d_wtns, r32, s32);
+    });
+}
+
+int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial) {
+    return guarded([&] {
+        if (!p || !partial) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        collect_sums_locked(p, partial);
     });
 }
 
 int zk_prove_collect(zk_prover *p, zk_proof *out) {
     return guarded([&] {
         if (!p || !out) throw std::invalid_argument("null argument");
+        if (p->shard_count != 1) throw std::invalid_argument("zk_prove_collect on a sharded prover: use zk_prove_msm_collect + zk_prove_finish");
         zk_msm_sums sums;
         uint8_t r32[32], s32[32];
         bool have_r, have_s;

@@ -99,6 +99,12 @@ class Prover:
         L.check(self._lib.zk_prove_collect(self._h, C.byref(out)))
         return bytes(out)
 
+    def collect_msm(self):
+        """Sharded provers: partial sums of the OLDEST submitted proof (zk_prove_msm_collect)."""
+        out = L.zk_msm_sums()
+        L.check(self._lib.zk_prove_msm_collect(self._h, C.byref(out)))
+        return bytes(out)
+
     def prove_msm(self, wtns):
         a = self._wtns_values(wtns)
         out = L.zk_msm_sums()
