@@ -76,4 +76,48 @@ void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n
     hipLaunchKernelGGL(k_spmv_abc, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, csr, wtns, n);
 }
 
+// ---- CSR build on the device (the reference has no such step: it walks the records under 1024
+// striped locks on every proof, src/groth16.cpp:63-84).  Records are 44-byte packed, 4-byte aligned.
+__global__ __launch_bounds__(256) void k_csr_count(uint32_t *rowcount, uint32_t *err, const uint32_t *rec, uint64_t nCoefs, uint32_t n,
+                                                   uint32_t nVars) {
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoefs; i += st) {
+        const uint32_t *r = rec + i * 11;
+        uint32_t m = r[0], c = r[1], sg = r[2];
+        if (m > 1u || c >= n || sg >= nVars) {
+            atomicOr(err, 1u);
+            continue;
+        }
+        atomicAdd(&rowcount[(uint64_t)m * n + c], 1u);
+    }
+}
+// The order of a row's terms depends on atomic arbitration; their (exact, modular) sum does not.
+__global__ __launch_bounds__(256) void k_csr_fill(uint32_t *col, Fr *val, uint32_t *cursor, const uint32_t *rec, uint64_t nCoefs, uint32_t n,
+                                                  uint32_t nVars) {
+    uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoefs; i += st) {
+        const uint32_t *r = rec + i * 11;
+        uint32_t m = r[0], c = r[1], sg = r[2];
+        if (m > 1u || c >= n || sg >= nVars) continue;
+        uint32_t pos = atomicAdd(&cursor[(uint64_t)m * n + c], 1u);
+        col[pos] = sg;
+        Fr v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v.v[j] = r[3 + j];
+        store_el(val + pos, v);
+    }
+}
+
+void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor, uint32_t *err, const uint8_t *records,
+                      uint64_t nCoefs, uint32_t n, uint32_t nVars, hipStream_t s) {
+    const uint32_t rows = 2 * n;
+    (void)hipMemsetAsync(cursor, 0, (size_t)rows * 4, s);
+    (void)hipMemsetAsync(err, 0, 4, s);
+    const uint32_t g = grid_for(nCoefs ? nCoefs : 1, 256, 256 * 16);
+    hipLaunchKernelGGL(k_csr_count, dim3(g), dim3(256), 0, s, cursor, err, (const uint32_t *)records, nCoefs, n, nVars);
+    launch_exclusive_scan_u32(rowptr, cursor, rows, s);
+    (void)hipMemcpyAsync(cursor, rowptr, (size_t)rows * 4, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, col, val, cursor, (const uint32_t *)records, nCoefs, n, nVars);
+}
+
 }   // namespace zk

@@ -20,6 +20,14 @@ struct CsrDev {
     const Fr *val;            // nnz: coefficient (value*R^2 as stored in the zkey)
 };
 void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s);
+// Row-sorted CSR from the zkey's coefficient records (section 4 after its u32 count: 44-byte packed
+// {u32 matrix, u32 row, u32 signal, 32-byte value}, src/groth16.hpp:27-35), built on the device.
+// rowptr: 2n + 1 words + msm_scan_extra_words(2n) of scan scratch; cursor: 2n words of scratch;
+// err: one word, set non-zero when a record is out of range (matrix > 1, row >= n, signal >= nVars).
+void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor, uint32_t *err, const uint8_t *records,
+                      uint64_t nCoefs, uint32_t n, uint32_t nVars, hipStream_t s);
+// exclusive scan: out[i] = sum counts[0..i), out[total] = grand total; out holds total + 1 + msm_scan_extra_words(total) words
+void launch_exclusive_scan_u32(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s);
 
 // ---------------------------------------------------------------- ntt.hip
 struct NttTables {

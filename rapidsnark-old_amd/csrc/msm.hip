@@ -667,6 +667,7 @@ static void launch_scan(uint32_t *out, const uint32_t *counts, uint32_t total, h
     hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, (const uint32_t *)block_sums, total);
 }
 uint32_t msm_scan_extra_words(uint32_t total) { return (total + SCAN_ELEMS - 1) / SCAN_ELEMS; }
+void launch_exclusive_scan_u32(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s) { launch_scan(out, counts, total, s); }
 
 // geometry of the two sort levels
 #define BIN_SHIFT 11u          // buckets per bin = 2^11 (see above)

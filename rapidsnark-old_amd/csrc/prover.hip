@@ -10,6 +10,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <chrono>
 #include <sys/random.h>
 #include <string>
 #include <vector>
@@ -205,35 +206,6 @@ uint32_t ilog2_exact(uint64_t n) {
     return l;
 }
 
-// Row-sorted CSR of the packed 44-byte Coef records (src/groth16.hpp:27-35), counting sort.
-void build_csr(const uint8_t *coefs /* after the u32 count */, uint64_t nCoefs, uint32_t n, uint32_t nVars,
-               std::vector<uint32_t> &rowptr, std::vector<uint32_t> &col, std::vector<uint8_t> &val) {
-    rowptr.assign((size_t)2 * n + 1, 0);
-    for (uint64_t i = 0; i < nCoefs; i++) {
-        const uint8_t *rec = coefs + i * 44;
-        uint32_t m, c, s;
-        memcpy(&m, rec, 4);
-        memcpy(&c, rec + 4, 4);
-        memcpy(&s, rec + 8, 4);
-        if (m > 1 || c >= n || s >= nVars) throw std::invalid_argument("zkey coefficient record out of range");
-        rowptr[(size_t)m * n + c + 1]++;
-    }
-    for (size_t r = 0; r < (size_t)2 * n; r++) rowptr[r + 1] += rowptr[r];
-    col.resize(nCoefs);
-    val.resize((size_t)nCoefs * 32);
-    std::vector<uint32_t> cur(rowptr.begin(), rowptr.end() - 1);
-    for (uint64_t i = 0; i < nCoefs; i++) {
-        const uint8_t *rec = coefs + i * 44;
-        uint32_t m, c, s;
-        memcpy(&m, rec, 4);
-        memcpy(&c, rec + 4, 4);
-        memcpy(&s, rec + 8, 4);
-        uint32_t pos = cur[(size_t)m * n + c]++;
-        col[pos] = s;
-        memcpy(&val[(size_t)pos * 32], rec + 12, 32);
-    }
-}
-
 // Device and pinned-host workspace of one in-flight proof.
 static void alloc_slot(zk_prover *p, int i) {
     zk_prover::ProofSlot &q = p->slot[i];
@@ -268,8 +240,23 @@ static void alloc_slot(zk_prover *p, int i) {
     q.allocated = true;
 }
 
+// ZKHIP_VERBOSE=1: phase times of zk_prover_create on stderr (the one-shot CLI pays create on every run)
+struct PhaseClock {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseClock() : on(getenv("ZKHIP_VERBOSE") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what, hipStream_t s) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[zkhip] create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     if (!out || !z) throw std::invalid_argument("null argument");
+    PhaseClock clk;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) throw std::runtime_error("no HIP device available (libzkhip has no CPU fallback)");
@@ -328,18 +315,31 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     HIP_TRY(hipStreamCreateWithFlags(&p->stream_fin, hipStreamNonBlocking));
     p->wbits = wbits;
     hipStream_t s = p->stream;
+    clk.lap("device + streams", s);
 
-    // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4)
-    std::vector<uint32_t> rowptr, col;
-    std::vector<uint8_t> val;
-    build_csr((const uint8_t *)z->coefs + 4, z->nCoefs, z->domainSize, z->nVars, rowptr, col, val);
-    p->csr_rowptr.alloc(rowptr.size());
-    p->csr_col.alloc(col.size() ? col.size() : 1);
-    p->csr_val.alloc(col.size() ? col.size() : 1);
-    p->csr_rowptr.upload(rowptr.data(), rowptr.size(), s);
-    p->csr_col.upload(col.data(), col.size(), s);
-    p->csr_val.upload(val.data(), col.size(), s);
-    launch_fr_to_internal(p->csr_val.p, col.size(), 2, s);      // value*2^512 -> value*2^522 (see k_spmv_abc)
+    // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4), built on the device from
+    // the raw records (the host pass over 4n random rows was the largest single part of create)
+    {
+        const uint64_t nnz = z->nCoefs;
+        const uint32_t rows = 2 * z->domainSize;
+        DevBuf<uint8_t> raw;
+        DevBuf<uint32_t> cursor, err;
+        raw.alloc(nnz ? nnz * 44 : 4);
+        cursor.alloc(rows);
+        err.alloc(1);
+        p->csr_rowptr.alloc((size_t)rows + 1 + msm_scan_extra_words(rows));
+        p->csr_col.alloc(nnz ? nnz : 1);
+        p->csr_val.alloc(nnz ? nnz : 1);
+        if (nnz) HIP_TRY(hipMemcpyAsync(raw.p, (const uint8_t *)z->coefs + 4, nnz * 44, hipMemcpyHostToDevice, s));
+        clk.lap("coefficient records upload", s);
+        launch_csr_build(p->csr_rowptr.p, p->csr_col.p, p->csr_val.p, cursor.p, err.p, raw.p, nnz, z->domainSize, z->nVars, s);
+        launch_fr_to_internal(p->csr_val.p, nnz, 2, s);      // value*2^512 -> value*2^522 (see k_spmv_abc)
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, err.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad) throw std::invalid_argument("zkey coefficient record out of range");
+        clk.lap("CSR build (device)", s);
+    }
 
     // --- twiddles
     p->tw_fwd.alloc(n > 1 ? n / 2 : 1);
@@ -347,6 +347,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->tw_coset.alloc(n);
     p->tw_ninv.alloc(1);
     launch_ntt_build_tables(p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p, p->logn, s);
+    clk.lap("twiddle tables", s);
 
     // --- point tables: this shard's contiguous slices
     p->sv = shard_slice(nV, p->shard_index, p->shard_count);
@@ -361,6 +362,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->ptsB1.alloc((nv ? nv : 1) * rows_w);
     p->ptsB2.alloc((nv ? nv : 1) * rows_w);
     p->ptsH.alloc((nh ? nh : 1) * rows_h);
+    clk.lap("workspace allocation", s);
     p->ptsA.upload((const uint8_t *)z->pointsA + p->sv.lo * 64, nv, s);
     p->ptsB1.upload((const uint8_t *)z->pointsB1 + p->sv.lo * 64, nv, s);
     p->ptsB2.upload((const uint8_t *)z->pointsB2 + p->sv.lo * 128, nv, s);
@@ -391,6 +393,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     launch_fq_to_internal((Fq *)p->ptsB1.p, nv * 2, s);
     launch_fq_to_internal((Fq *)p->ptsB2.p, nv * 4, s);
     launch_fq_to_internal((Fq *)p->ptsH.p, nh * 2, s);
+    clk.lap("point tables upload+convert", s);
     if (p->precomp) {
         // one scratch area for the doubling walks, reused table after table (freed on return)
         const MsmPlan plan_w = p->slot[0].sort_w.plan;
@@ -413,6 +416,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->abc.alloc(3 * n);
     p->h.alloc(n);
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
+    clk.lap(p->precomp ? "window pre-computation" : "finish", s);
     *out = p.release();
 }
 

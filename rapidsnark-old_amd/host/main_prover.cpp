@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <optional>
@@ -54,7 +55,20 @@ std::string public_signals_json(const uint8_t *witness, uint32_t nPublic) {
     return s;
 }
 
+// ZKHIP_VERBOSE=1: phase times on stderr
+struct Lap {
+    bool on = getenv("ZKHIP_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        std::cerr << "[prover] " << what << ": " << std::chrono::duration<double, std::milli>(now - t).count() << " ms\n";
+        t = now;
+    }
+};
+
 int run(const std::string &zkeyPath, const std::string &wtnsPath, const std::string &proofPath, const std::string &publicPath) {
+    Lap lap;
     auto zkey = BinFileUtils::openExisting(zkeyPath, "zkey", 1);
     auto zh = ZKeyUtils::loadHeader(zkey.get());
     if (!is_bn254_r(zh->rPrime)) throw std::invalid_argument("zkey curve not supported");
@@ -66,6 +80,7 @@ int run(const std::string &zkeyPath, const std::string &wtnsPath, const std::str
     if (wh->nVars != zh->nVars || wtns->getSectionSize(2) < uint64_t(zh->nVars) * 32)
         throw std::invalid_argument("witness does not match the zkey (nVars)");
 
+    lap("open zkey + wtns");
     uint64_t bytes[6];
     for (uint32_t sec = 4; sec <= 9; sec++) bytes[sec - 4] = zkey->getSectionSize(sec);
     auto prover = Groth16::makeProver(zh->nVars, zh->nPublic, zh->domainSize, zh->nCoefs, zh->vk_alpha1, zh->vk_beta1, zh->vk_beta2,
@@ -78,12 +93,15 @@ int run(const std::string &zkeyPath, const std::string &wtnsPath, const std::str
                                       zkey->getSectionData(9),   // H
                                       bytes);
 
+    lap("makeProver");
     const auto *witness = static_cast<const uint8_t *>(wtns->getSectionData(2));
     const auto r = scalar_from_env("ZKHIP_FIXED_R"), s = scalar_from_env("ZKHIP_FIXED_S");
     auto proof = prover->prove(witness, r ? r->b : nullptr, s ? s->b : nullptr);
 
+    lap("prove");
     write_text(proofPath, proof->toJson());
     write_text(publicPath, public_signals_json(witness, zh->nPublic));
+    lap("write json");
     return 0;
 }
 
