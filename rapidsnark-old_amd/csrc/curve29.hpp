@@ -102,4 +102,100 @@ ZK_HD void negate_y(Affine<Fq2r> &p) {
     p.y.b = Fq29::neg_lazy(p.y.b);
 }
 
+
+#if defined(__HIPCC__)
+// ---- Fq2 split across a lane pair (device only): lane 2k holds the real component, lane 2k+1 the
+// imaginary one, and each computes ONE fused double product per Fq2 multiplication after a DPP
+// quad-permute exchange of the operands.  The arithmetic is operand-for-operand the one of
+// Fp2T<Fq29> (same products, same carries, same results); what changes is the register file: a
+// G2 accumulator needs the registers of a G1 one (3 waves/SIMD instead of 1).  Control flow must be
+// uniform inside a pair: every predicate below is the AND over both lanes.
+struct Fq2s {
+    Fq29 v;
+    static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ int xchg(int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
+    static __device__ __forceinline__ Fq29 other(const Fq29 &a) {
+        Fq29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = xchg(a.l[i]);
+        return r;
+    }
+    static __device__ __forceinline__ Fq29 sel(bool c, const Fq29 &a, const Fq29 &b) {   // c ? a : b
+        Fq29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : b.l[i];
+        return r;
+    }
+    static __device__ __forceinline__ bool both(bool mine) { return mine && xchg(mine ? 1 : 0) != 0; }
+    static __device__ __forceinline__ Fq2s zero() { return Fq2s{Fq29::zero()}; }
+    static __device__ __forceinline__ Fq2s one() { return Fq2s{sel(odd(), Fq29::zero(), Fq29::one())}; }
+    __device__ __forceinline__ bool is_zero() const { return both(v.is_zero()); }
+    __device__ __forceinline__ bool is_zero_raw() const { return both(v.is_zero_raw()); }
+    static __device__ __forceinline__ Fq2s add(const Fq2s &x, const Fq2s &y) { return Fq2s{Fq29::add(x.v, y.v)}; }
+    static __device__ __forceinline__ Fq2s sub(const Fq2s &x, const Fq2s &y) { return Fq2s{Fq29::sub(x.v, y.v)}; }
+    static __device__ __forceinline__ Fq2s neg(const Fq2s &x) { return Fq2s{Fq29::neg(x.v)}; }
+    static __device__ __forceinline__ Fq2s dbl(const Fq2s &x) { return Fq2s{Fq29::dbl(x.v)}; }
+    static __device__ __forceinline__ Fq29 from_even(const Fq29 &a) {   // both lanes: the even lane's value (quad_perm [0,0,2,2])
+        Fq29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], 0xA0, 0xF, 0xF, true);
+        return r;
+    }
+    static __device__ __forceinline__ Fq29 from_odd(const Fq29 &a) {    // both lanes: the odd lane's value (quad_perm [1,1,3,3])
+        Fq29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], 0xF5, 0xF, 0xF, true);
+        return r;
+    }
+    // re = a0 b0 - a1 b1 (even lane), im = a0 b1 + a1 b0 (odd lane): with y = own component of b and
+    // yo = the partner's, both are  a0 * y + (+-a1) * yo  — one instruction stream, no operand selects
+    static __device__ __forceinline__ Fq2s mul(const Fq2s &x, const Fq2s &y) {
+        const Fq29 a0 = from_even(x.v), a1 = from_odd(x.v), yo = other(y.v);
+        return Fq2s{Fq29::mul_add2(a0, y.v, sel(odd(), a1, Fq29::neg_lazy(a1)), yo)};
+    }
+    // re = (a0 + a1)(a0 - a1), im = 2 a0 a1 = (a0 + a0) * a1:  u = a0 + partner, w = own - (even ? a1 : 0)
+    static __device__ __forceinline__ Fq2s sqr(const Fq2s &x) {
+        const Fq29 a0 = from_even(x.v), xo = other(x.v);
+        const int keep = odd() ? 0 : -1;
+        Fq29 t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.l[i] = xo.l[i] & keep;
+        return Fq2s{Fq29::mul(Fq29::add_nc(a0, xo), Fq29::sub(x.v, t))};
+    }
+};
+
+// the bound-tracked mixed add of XYZZ<Fq2r> above, one component per lane
+__device__ __forceinline__ void madd(XYZZ<Fq2s> &acc, const Affine<Fq2s> &p) {
+    typedef Fq29 B;
+    typedef Fq2s F;
+    if (p.is_inf()) return;
+    if (acc.is_inf()) {
+        acc = XYZZ<F>{p.x, F{B::carry(p.y.v)}, F::one(), F::one()};
+        return;
+    }
+    F U2 = F::mul(p.x, acc.zz);
+    F S2 = F::mul(p.y, acc.zzz);
+    F P{B::sub_nc(U2.v, acc.x.v)};
+    F R{B::sub_nc(S2.v, acc.y.v)};
+    if (P.is_zero()) {
+        if (R.is_zero()) acc = dbl_affine(Affine<F>{p.x, F{B::carry(p.y.v)}});
+        else acc = XYZZ<F>::inf();
+        return;
+    }
+    F PP = F::sqr(P);
+    acc.zz = F::mul(acc.zz, PP);
+    F Q = F::mul(acc.x, PP);
+    F PPP = F::mul(P, PP);
+    acc.zzz = F::mul(acc.zzz, PPP);
+    F T2 = F::mul(acc.y, PPP);
+    F R2 = F::sqr(R);
+#pragma unroll
+    for (int i = 0; i < 9; i++) acc.x.v.l[i] = R2.v.l[i] - PPP.v.l[i] - (Q.v.l[i] << 1);
+    acc.x.v = B::carry(acc.x.v);                  // X3
+    F D{B::sub_nc(Q.v, acc.x.v)};
+    F T1 = F::mul(R, D);
+    acc.y = F{B::sub(T1.v, T2.v)};                // carried: keeps the next S2 - y tight
+}
+#endif
+
 }   // namespace zk

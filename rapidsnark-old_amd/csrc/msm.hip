@@ -516,6 +516,90 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
     out_flag[2 * (uint64_t)t + 1] = tflag;
 }
 
+// G2 level 1 with the accumulator split across lane pairs (curve29.hpp, Fq2s): two lanes per chunk,
+// lane parity = Fq2 component.  Both lanes of a pair walk the same entries, so the loop and every
+// branch are uniform inside the pair (the DPP exchanges need both lanes active).
+__global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries,
+                                                          const G2Affine *points, uint32_t idx_min, uint32_t idx_sub,
+                                                          uint32_t nbuckets_total, G2XYZZ *out_part, uint32_t *out_key,
+                                                          uint32_t *out_flag, uint32_t nlanes, uint32_t ACC_CHUNK) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt >> 1, comp = gt & 1u;          // chunk, component (blockDim is even: comp == threadIdx.x & 1)
+    if (t >= nlanes) return;
+    const uint32_t E = offsets[nbuckets_total];
+    const uint64_t lo64 = (uint64_t)t * ACC_CHUNK;
+    uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
+    auto store_comp = [&](G2XYZZ *dst, const XYZZ<Fq2s> &v) {     // memory: x.a x.b y.a y.b zz.a zz.b zzz.a zzz.b
+        Fq *d = reinterpret_cast<Fq *>(dst) + comp;
+        Reg<Fq>::store(d, v.x.v);
+        Reg<Fq>::store(d + 2, v.y.v);
+        Reg<Fq>::store(d + 4, v.zz.v);
+        Reg<Fq>::store(d + 6, v.zzz.v);
+    };
+    if (lo64 < E) {
+        const uint32_t lo = (uint32_t)lo64;
+        const uint32_t hi = (E - lo > ACC_CHUNK) ? lo + ACC_CHUNK : E;
+        uint32_t bl = 0, br = nbuckets_total - 1;
+        while (bl < br) {
+            uint32_t mid = (bl + br + 1) >> 1;
+            if (offsets[mid] <= lo) bl = mid; else br = mid - 1;
+        }
+        uint32_t b = bl;
+        uint32_t bend = offsets[b + 1];
+        bool started_before = offsets[b] < lo;
+        XYZZ<Fq2s> acc = XYZZ<Fq2s>::inf();
+        Fq nextX, nextY;                 // raw words of this lane's component of the next point
+        bool nextNeg = false, nextSkip = false;
+        auto fetch = [&](uint32_t pos) {
+            uint32_t ent = entries[pos];
+            uint32_t idx = ent & 0x7fffffffu;
+            nextNeg = (ent >> 31) != 0;
+            nextSkip = idx < idx_min;
+            const Fq *src = reinterpret_cast<const Fq *>(points + (nextSkip ? 0 : idx - idx_sub)) + comp;
+            nextX = load_el(src);
+            nextY = load_el(src + 2);
+        };
+        uint32_t e = lo;
+        fetch(e);
+        while (e < hi) {
+            Fq Xw = nextX, Yw = nextY;
+            bool ng = nextNeg, skip = nextSkip;
+            e++;
+            if (e < hi) fetch(e);
+            if (!skip) {
+                Affine<Fq2s> P{Fq2s{Fq29::load(Xw)}, Fq2s{Fq29::load(Yw)}};
+                if (ng) P.y.v = Fq29::neg_lazy(P.y.v);
+                madd(acc, P);
+            }
+            if (e == bend || e == hi) {
+                const bool ends = (e == bend);
+                if (!started_before && ends) {
+                    store_comp(buckets + b, acc);
+                } else if (started_before) {
+                    store_comp(out_part + 2 * (uint64_t)t, acc);
+                    hkey = b;
+                    hflag = ends ? FLAG_ENDS : 0u;
+                } else {
+                    store_comp(out_part + 2 * (uint64_t)t + 1, acc);
+                    tkey = b;
+                    tflag = FLAG_STARTS;
+                }
+                if (e < hi) {
+                    do { b++; bend = offsets[b + 1]; } while (bend == e);
+                    started_before = false;
+                    acc = XYZZ<Fq2s>::inf();
+                }
+            }
+        }
+    }
+    if (comp == 0) {
+        out_key[2 * (uint64_t)t] = hkey;
+        out_flag[2 * (uint64_t)t] = hflag;
+        out_key[2 * (uint64_t)t + 1] = tkey;
+        out_flag[2 * (uint64_t)t + 1] = tflag;
+    }
+}
+
 // Pairwise merge between level 1 and the generic levels: a bucket cut by exactly ONE chunk edge
 // (the overwhelmingly common case — mean run length ~ chunk length) is the TAIL slot of lane t
 // plus the HEAD slot of lane t+1 that also ENDS.  One general add per lane, full occupancy,
@@ -817,9 +901,21 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
     (void)hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s);
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
     if (ev) (void)hipEventRecord(ev[0], s);           // tight bracket around the level-1 kernel (roofline timing)
-    hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
-                       points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
-                       accum_chunk_for(max_entries ? max_entries : 1));
+    if constexpr (sizeof(F) == sizeof(Fq2)) {
+        static const bool split = !(getenv("ZKHIP_G2_SPLIT") && atoi(getenv("ZKHIP_G2_SPLIT")) == 0);   // tuning aid
+        if (split)
+            hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
+                               points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
+                               accum_chunk_for(max_entries ? max_entries : 1));
+        else
+            hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
+                               points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
+                               accum_chunk_for(max_entries ? max_entries : 1));
+    } else {
+        hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
+                           points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
+                           accum_chunk_for(max_entries ? max_entries : 1));
+    }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (tail.stream && tail.stream != s) {            // partial merges continue on the caller's follow-up stream
         (void)hipEventRecord(tail.l1_done, s);
