@@ -23,8 +23,13 @@ for mode in (0, 1):
     ts = []
     for _ in range(3):
         t = time.time(); p.prove_dev(w.data_ptr(), r, s); ts.append(time.time() - t)
+    # two proofs in flight (second ProofSlot) must give the same bytes
+    p.submit_dev(w.data_ptr()); p.submit_dev(w.data_ptr())
+    t = time.time(); p.collect(); p.submit_dev(w.data_ptr()); p.collect(); p.collect(); tp = (time.time() - t) / 2
     out[mode] = proof
+    print("   pipelined period ~%.1f ms" % (tp * 1e3), flush=True)
     print("precomp=%d create %.2f s  prove %.1f ms  free HBM %.1f GB" % (mode, tc, min(ts) * 1e3, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+    p.lib.zk_prover_destroy(p.h)
     del p
 print("proofs identical:", out[0] == out[1])
 print(zk.proof_to_json(out[1])[:120], "...")
