@@ -150,6 +150,12 @@ int zk_msm_g2(uint8_t out[128], const uint8_t *bases, const uint8_t *scalars, ui
 /* out[i] = P0 + i*Q, affine Montgomery, generated on the GPU (host output buffer). */
 int zk_synth_chain_g1(uint8_t *out, uint64_t n, const uint8_t p0[64], const uint8_t q[64]);
 int zk_synth_chain_g2(uint8_t *out, uint64_t n, const uint8_t p0[128], const uint8_t q[128]);
+/* Batch fixed-base multiplication out[i] = scalars[i] * base (affine Montgomery out, scalars n x 32 B
+ * LE standard form, 0 -> all-zero infinity encoding), on the GPU.  What a Groth16 setup does with the
+ * evaluations A_i(tau), B_i(tau), ... (snarkjs zkey sections 5-9 as consumed at src/main_prover.cpp:67-72):
+ * with it trapdoor-valid keys at benchmark sizes take seconds. */
+int zk_fixed_base_g1(uint8_t *out, const uint8_t base[64], const uint8_t *scalars, uint64_t n);
+int zk_fixed_base_g2(uint8_t *out, const uint8_t base[128], const uint8_t *scalars, uint64_t n);
 /* out = k*P — Curve::mulByScalar (src/groth16.cpp:223) on the host; k: 32 B LE standard form. */
 int zk_g1_mul(uint8_t out[64], const uint8_t p[64], const uint8_t k[32]);
 int zk_g2_mul(uint8_t out[128], const uint8_t p[128], const uint8_t k[32]);

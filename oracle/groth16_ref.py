@@ -165,13 +165,11 @@ def _lagrange_at(tau, n):
     return out
 
 
-def setup(r1cs: R1CS, toxic, domain_size=None):
-    """Trapdoor Groth16 setup in the snarkjs zkey layout.
-
-    toxic = (tau, alpha, beta, gamma, delta).  Returns (ZKey, trap) where trap holds
-    the per-signal polynomial evaluations at tau used by `trapdoor_check`.
-    snarkjs appends nPublic+1 rows A[m+i][i] = 1.
-    """
+def setup_scalars(r1cs: R1CS, toxic, domain_size=None):
+    """The Fr half of a trapdoor Groth16 setup in the snarkjs zkey layout: every
+    table entry's discrete logarithm, no curve arithmetic.  snarkjs appends nPublic+1 rows
+    A[m+i][i] = 1.  Returns the dict `trap` used by `trapdoor_check`, plus
+    "coefs" (m, c, s, value), "IC" and "C" scalars."""
     tau, alpha, beta, gamma, delta = toxic
     m = len(r1cs.A)
     need = m + r1cs.nPublic + 1
@@ -196,21 +194,7 @@ def setup(r1cs: R1CS, toxic, domain_size=None):
             Ct[s] = (Ct[s] + v * L[row]) % R_MOD
     ginv = pow(gamma, -1, R_MOD)
     dinv = pow(delta, -1, R_MOD)
-    t1 = G1.fixed_base_table(G1.gen)
-    t2 = G2.fixed_base_table(G2.gen)
-    g1 = lambda k: G1.mul_fixed(t1, k % R_MOD)
-    g2 = lambda k: G2.mul_fixed(t2, k % R_MOD)
-    zk = ZKey()
-    zk.nVars, zk.nPublic, zk.domainSize = r1cs.nVars, r1cs.nPublic, n
-    zk.alpha1, zk.beta1, zk.delta1 = g1(alpha), g1(beta), g1(delta)
-    zk.beta2, zk.gamma2, zk.delta2 = g2(beta), g2(gamma), g2(delta)
-    zk.coefs = coefs
-    zk.A = [g1(x) for x in At]
-    zk.B1 = [g1(x) for x in Bt]
-    zk.B2 = [g2(x) for x in Bt]
     K = [(beta * At[i] + alpha * Bt[i] + Ct[i]) % R_MOD for i in range(r1cs.nVars)]
-    zk.IC = [g1(K[i] * ginv) for i in range(r1cs.nPublic + 1)]
-    zk.C = [g1(K[i] * dinv) for i in range(r1cs.nPublic + 1, r1cs.nVars)]
     # H[i] = L^(2n)_{2i+1}(tau)/delta * G1  
     w2n = bn.fr_root(n.bit_length())          # primitive 2n-th root
     z2 = (pow(tau, 2 * n, R_MOD) - 1) % R_MOD
@@ -219,8 +203,33 @@ def setup(r1cs: R1CS, toxic, domain_size=None):
     for i in range(n):
         wj = pow(w2n, 2 * i + 1, R_MOD)
         Hs.append(z2 * wj % R_MOD * inv2n % R_MOD * pow((tau - wj) % R_MOD, -1, R_MOD) % R_MOD * dinv % R_MOD)
-    zk.H = [g1(x) for x in Hs]
-    trap = {"At": At, "Bt": Bt, "Ct": Ct, "K": K, "Hs": Hs, "toxic": toxic, "n": n}
+    return {"At": At, "Bt": Bt, "Ct": Ct, "K": K, "Hs": Hs, "toxic": toxic, "n": n, "coefs": coefs,
+            "IC": [K[i] * ginv % R_MOD for i in range(r1cs.nPublic + 1)],
+            "C": [K[i] * dinv % R_MOD for i in range(r1cs.nPublic + 1, r1cs.nVars)]}
+
+
+def setup(r1cs: R1CS, toxic, domain_size=None):
+    """Trapdoor Groth16 setup: `setup_scalars` + fixed-base multiplications of the generators.
+
+    toxic = (tau, alpha, beta, gamma, delta).  Returns (ZKey, trap) where trap holds
+    the per-signal polynomial evaluations at tau used by `trapdoor_check`."""
+    tau, alpha, beta, gamma, delta = toxic
+    trap = setup_scalars(r1cs, toxic, domain_size)
+    t1 = G1.fixed_base_table(G1.gen)
+    t2 = G2.fixed_base_table(G2.gen)
+    g1 = lambda k: G1.mul_fixed(t1, k % R_MOD)
+    g2 = lambda k: G2.mul_fixed(t2, k % R_MOD)
+    zk = ZKey()
+    zk.nVars, zk.nPublic, zk.domainSize = r1cs.nVars, r1cs.nPublic, trap["n"]
+    zk.alpha1, zk.beta1, zk.delta1 = g1(alpha), g1(beta), g1(delta)
+    zk.beta2, zk.gamma2, zk.delta2 = g2(beta), g2(gamma), g2(delta)
+    zk.coefs = trap["coefs"]
+    zk.A = [g1(x) for x in trap["At"]]
+    zk.B1 = [g1(x) for x in trap["Bt"]]
+    zk.B2 = [g2(x) for x in trap["Bt"]]
+    zk.IC = [g1(x) for x in trap["IC"]]
+    zk.C = [g1(x) for x in trap["C"]]
+    zk.H = [g1(x) for x in trap["Hs"]]
     return zk, trap
 
 

@@ -117,5 +117,8 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s);
 // ---------------------------------------------------------------- synth.hip
 void launch_chain_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &P0, const G1Affine &Q, uint64_t n, hipStream_t s);
 void launch_chain_g2(G2Affine *d_out, G2XYZZ *d_tmp, Fq2 *d_pref, const G2Affine &P0, const G2Affine &Q, uint64_t n, hipStream_t s);
+// out[i] = scalars[i] * B  (scalars: n x 8 little-endian words, standard form)
+void launch_fixed_base_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s);
+void launch_fixed_base_g2(G2Affine *d_out, G2XYZZ *d_tmp, Fq2 *d_pref, const G2Affine &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s);
 
 }   // namespace zk

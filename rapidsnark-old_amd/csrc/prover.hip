@@ -848,7 +848,35 @@ static void synth_chain(uint8_t *out, uint64_t n, const uint8_t *p0, const uint8
     HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(AffT), hipMemcpyDeviceToHost));
 }
 
+template <class AffT, class XT, class FT>
+static void fixed_base_batch(uint8_t *out, const uint8_t *base, const uint8_t *scalars, uint64_t n,
+                             void (*launch)(AffT *, XT *, FT *, const AffT &, const uint32_t *, uint64_t, hipStream_t)) {
+    need_device();
+    if (!n) return;
+    if (!out || !base || !scalars) throw std::invalid_argument("null argument");
+    DevBuf<AffT> d_out;
+    DevBuf<XT> d_tmp;
+    DevBuf<FT> d_pref;
+    DevBuf<uint32_t> d_sc;
+    d_out.alloc(n);
+    d_tmp.alloc(n);
+    d_pref.alloc(n);
+    d_sc.alloc(n * 8);
+    AffT B;
+    memcpy(&B, base, sizeof(AffT));
+    HIP_TRY(hipMemcpy(d_sc.p, scalars, n * 32, hipMemcpyHostToDevice));
+    launch(d_out.p, d_tmp.p, d_pref.p, B, d_sc.p, n, 0);
+    HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(AffT), hipMemcpyDeviceToHost));
+}
+
 extern "C" {
+
+int zk_fixed_base_g1(uint8_t *out, const uint8_t base[64], const uint8_t *scalars, uint64_t n) {
+    return guarded([&] { fixed_base_batch<G1Affine, G1XYZZ, Fq>(out, base, scalars, n, launch_fixed_base_g1); });
+}
+int zk_fixed_base_g2(uint8_t *out, const uint8_t base[128], const uint8_t *scalars, uint64_t n) {
+    return guarded([&] { fixed_base_batch<G2Affine, G2XYZZ, Fq2>(out, base, scalars, n, launch_fixed_base_g2); });
+}
 
 int zk_synth_chain_g1(uint8_t *out, uint64_t n, const uint8_t p0[64], const uint8_t q[64]) {
     return guarded([&] { synth_chain<G1Affine, G1XYZZ, Fq>(out, n, p0, q, launch_chain_g1); });

@@ -82,6 +82,37 @@ static void chain(Affine<F> *d_out, XYZZ<F> *d_tmp, F *d_pref, const Affine<F> &
     hipLaunchKernelGGL(k_chain_normalize<F>, dim3(blocks), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
 }
 
+// Batch fixed-base multiplication out[i] = k_i * B (a trapdoor-valid zkey is nothing but
+// five such batches over the evaluations A_i(tau), B_i(tau), ... computed in Fr).  One lane per
+// scalar, plain double-and-add over all 256 bits (no table: 5 x 2^20 points take well under a second),
+// then the same batched normalisation as the chains.  k_i = 0 gives the all-zero infinity encoding.
+template <class F>
+__global__ __launch_bounds__(64) void k_fixed_base(XYZZ<F> *tmp, Affine<F> B, const uint32_t *scalars, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = scalars[i * 8 + j];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 255; bit >= 0; bit--) {
+        acc = dbl(acc);
+        if ((k[bit >> 5] >> (bit & 31)) & 1u) madd(acc, B);
+    }
+    st(&tmp[i].x, acc.x); st(&tmp[i].y, acc.y); st(&tmp[i].zz, acc.zz); st(&tmp[i].zzz, acc.zzz);
+}
+template <class F>
+static void fixed_base(Affine<F> *d_out, XYZZ<F> *d_tmp, F *d_pref, const Affine<F> &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_fixed_base<F>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, d_tmp, B, d_scalars, n);
+    uint64_t segs = (n + CHAIN_SEG - 1) / CHAIN_SEG;
+    hipLaunchKernelGGL(k_chain_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
+}
+void launch_fixed_base_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s) {
+    fixed_base<Fq>(d_out, d_tmp, d_pref, B, d_scalars, n, s);
+}
+void launch_fixed_base_g2(G2Affine *d_out, G2XYZZ *d_tmp, Fq2 *d_pref, const G2Affine &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s) {
+    fixed_base<Fq2>(d_out, d_tmp, d_pref, B, d_scalars, n, s);
+}
+
 void launch_chain_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &P0, const G1Affine &Q, uint64_t n, hipStream_t s) {
     chain<Fq>(d_out, d_tmp, d_pref, P0, Q, n, s);
 }

@@ -49,7 +49,7 @@ ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "ms
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
            "zk_prove_dev_submit", "zk_prove_collect", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
-           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble"]
+           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble"]
 
 
 def load_library():
@@ -91,6 +91,8 @@ def load_library():
     lib.zk_msm_g2.argtypes = [u8p, u8p, u8p, C.c_uint64]
     lib.zk_synth_chain_g1.argtypes = [u8p, C.c_uint64, u8p, u8p]
     lib.zk_synth_chain_g2.argtypes = [u8p, C.c_uint64, u8p, u8p]
+    lib.zk_fixed_base_g1.argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_fixed_base_g2.argtypes = [u8p, u8p, u8p, C.c_uint64]
     lib.zk_g1_mul.argtypes = [u8p, u8p, u8p]
     lib.zk_g2_mul.argtypes = [u8p, u8p, u8p]
     lib.zk_proof_to_json.argtypes = [C.POINTER(zk_proof), C.c_char_p, C.c_size_t]
@@ -201,6 +203,32 @@ def synth_chain_g2(n, p0, q):
     out = np.zeros(n * 128, dtype=np.uint8)
     a, b = _buf(p0).copy(), _buf(q).copy()
     check(load_library().zk_synth_chain_g2(_ptr(out), n, _ptr(a), _ptr(b)))
+    return out
+
+
+def _scalars_le(scalars):
+    if isinstance(scalars, np.ndarray) and scalars.dtype == np.uint8:
+        return np.ascontiguousarray(scalars)
+    return np.frombuffer(b"".join(int(k).to_bytes(32, "little") for k in scalars), dtype=np.uint8).copy()
+
+
+def fixed_base_g1(base, scalars):
+    """[k*base for k in scalars] on the GPU -> numpy uint8 [n*64] (affine Montgomery; 0 -> all-zero).
+    scalars: iterable of ints < 2^256, or uint8 array n*32 (LE standard form)."""
+    sc = _scalars_le(scalars)
+    n = sc.size // 32
+    out = np.zeros(n * 64, dtype=np.uint8)
+    b = _buf(base).copy()
+    check(load_library().zk_fixed_base_g1(_ptr(out), _ptr(b), _ptr(sc), n))
+    return out
+
+
+def fixed_base_g2(base, scalars):
+    sc = _scalars_le(scalars)
+    n = sc.size // 32
+    out = np.zeros(n * 128, dtype=np.uint8)
+    b = _buf(base).copy()
+    check(load_library().zk_fixed_base_g2(_ptr(out), _ptr(b), _ptr(sc), n))
     return out
 
 

@@ -164,3 +164,47 @@ def test_precomp_mode_matches_plain_mode(zk, k, wbits):
         wd = torch.from_numpy(w).to("cuda:0")
         base = _prover(zk, wl).prove_msm_dev(wd.data_ptr())
         assert _prover(zk, wl, precomp=True, window_bits=wbits).prove_msm_dev(wd.data_ptr()) == base
+
+
+def test_fixed_base_batch_matches_host_scalar_mul(zk):
+    """zk_fixed_base_g1/g2 against the host scalar multiplication (independent 4x64-bit code) and the
+    oracle, including 0, 1, r-1 and a 256-bit value >= r."""
+    import random
+    rng = random.Random(99)
+    ks = [0, 1, 2, bn.R_MOD - 1, bn.R_MOD, (1 << 256) - 1] + [rng.randrange(bn.R_MOD) for _ in range(70)]
+    g1 = zk.fixed_base_g1(G1B, ks).tobytes()
+    g2 = zk.fixed_base_g2(G2B, ks).tobytes()
+    for i, k in enumerate(ks):
+        assert g1[64 * i:64 * i + 64] == bn.g1_to_bytes(bn.G1.mul(bn.G1.gen, k % bn.R_MOD)), i
+        assert g2[128 * i:128 * i + 128] == bn.g2_to_bytes(bn.G2.mul(bn.G2.gen, k % bn.R_MOD)), i
+
+
+@pytest.mark.parametrize("k,precomp", [(10, False), (14, True), (16, True)])
+def test_valid_key_at_scale_passes_trapdoor_check(zk, tmp_path, k, precomp):
+    """a trapdoor-VALID key over a random satisfiable R1CS with a 2^k domain (tables from
+    the GPU fixed-base kernel), a satisfying witness, and the proof identity of §8c item 2 checked in Fr:
+    A = a*G1, B = b*G2, C = c*G1 with (a, b, c) computed from the toxic waste.  The same proof must come
+    out of the C restatement (bit-exact) and of the one-shot CLI on the written .zkey / .wtns."""
+    import os
+    import subprocess
+    import valid_key as vk
+    from conftest import ROOT
+    wl, wit, trap, w = vk.build(zk, k, seed=1000 + k)
+    zpath, wpath = tmp_path / "valid.zkey", tmp_path / "valid.wtns"
+    zpath.write_bytes(vk.zkey_bytes(wl))
+    wpath.write_bytes(vk.wtns_bytes(wl, wit))
+    r, s = 0x0123456789ABCDEF0123, (1 << 247) - 12345
+    p = zk.Prover(str(zpath), precomp=precomp)
+    proof = p.prove(wpath.read_bytes(), r=r, s=s)
+    p.close()
+    a, b, c = vk.expected_proof_dlogs(trap, wl["nPublic"], w, r, s)
+    assert proof[0:64] == zk.g1_mul(G1B, a)
+    assert proof[64:192] == zk.g2_mul(G2B, b)
+    assert proof[192:256] == zk.g1_mul(G1B, c)
+    assert proof == co.prove(co.ZkeyView(wl), wit, r, s)
+    env = dict(os.environ, ZKHIP_FIXED_R=int(r).to_bytes(32, "little").hex(), ZKHIP_FIXED_S=int(s).to_bytes(32, "little").hex())
+    out = subprocess.run([os.path.join(ROOT, "rapidsnark-old_amd", "prover"), str(zpath), str(wpath), str(tmp_path / "p.json"), str(tmp_path / "q.json")],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert (tmp_path / "p.json").read_text() == zk.proof_to_json(proof)
+    assert (tmp_path / "q.json").read_text() == zk.public_to_json(wit, wl["nPublic"])
