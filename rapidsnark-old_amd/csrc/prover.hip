@@ -298,12 +298,13 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     if (getenv("ZKHIP_SERIAL")) p->stream2 = p->stream;
     else HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
     {
-        // Follow-up streams (highest priority) for the partial merges and bucket reductions: with
-        // long level-1 kernels these small kernels otherwise queue behind the next level-1 launch
-        // of their own stream and pile up after the last one (2^22: 44.0 -> 43.1 ms; at 2^20 the
-        // extra cross-stream hand-offs cost more than they save).  ZKHIP_TAIL=0/1 overrides.
+        // Follow-up streams (highest priority) for the partial merges and bucket reductions: on
+        // the streams of their MSMs these small kernels queue behind the next level-1 launch and
+        // pile up after the last one.  Measured with two proofs in flight: 2^22 39.7 -> 39.1 ms
+        // (same box), 2^20 15.8 -> 13.5 ms, a shard of 8 at 2^22 12.4 -> 11.3 ms; one proof at a
+        // time it is neutral from 2^20 up (2^18: 7.6 -> 8.0 ms).  ZKHIP_TAIL=0 turns them off.
         const char *e = getenv("ZKHIP_TAIL");
-        bool follow = e ? atoi(e) != 0 : (uint64_t)z->domainSize * 13 >= (1ull << 25);
+        bool follow = e ? atoi(e) != 0 : true;
         if (getenv("ZKHIP_SERIAL")) follow = false;
         if (follow) {
             int lo_pr = 0, hi_pr = 0;
@@ -495,7 +496,9 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, co
     launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, q.acc_ws_g1[3].p, q.acc_key[3].p, q.acc_flag[3].p, s, nullptr, tail_of(3));
     mark(4);
     launch_msm_reduce_g1(q.wsum_g1.p + 3 * Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, pw), bH, 1, p->sort_h.plan, after(s));
-    // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w)
+    // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w).  (Moving it to
+    // stream2 was measured slower at every shard count; so was raising stream 1's priority for
+    // anything but the two-in-flight throughput of 4-8 shards.)
     HIP_TRY(hipStreamWaitEvent(s, q.ev_sortw, 0));
     launch_msm_accum_g1(bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, q.acc_ws_g1[2].p, q.acc_key[2].p, q.acc_flag[2].p, s, nullptr, tail_of(2));
     launch_msm_reduce_g1(q.wsum_g1.p + 2 * Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, pw), bC, 1, pw, after(s));
