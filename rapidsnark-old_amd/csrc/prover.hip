@@ -425,6 +425,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
 // d_wtns: device pointer, nVars x 32 B, must stay valid until the proof is collected.
 // Caller holds p->mtx.
 static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, const uint8_t *s32) {
+    const bool staged = d_wtns == p->wtns.p;      // witness staged by an H2D copy on `stream` (zk_prove / zk_prove_msm)
     if (p->in_flight >= 2) throw std::invalid_argument("two proofs already in flight: collect one first");
     DeviceGuard g(p->device);
     const int si = (int)(p->next_submit & 1u);
@@ -452,8 +453,13 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, co
     // ---- stream2: work that depends on the witness only (the reference runs it AFTER the FFT
     // chain, src/groth16.cpp:180-204; it is independent of it): sort(w) once, then MSM B2, A, B1
     // over the shared bucket order.  MSM C joins stream 1 behind MSM H to balance the streams.
-    HIP_TRY(hipEventRecord(q.ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(s2, q.ev_fork, 0));
+    // stream2 depends on stream 1 only through a staged witness: with a caller-owned device witness
+    // it runs ahead, so that proof k+1's witness MSMs follow proof k's directly instead of waiting
+    // for proof k's stream-1 work (at 2^20 that wait left stream2 idle for a third of the period)
+    if (staged) {
+        HIP_TRY(hipEventRecord(q.ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(s2, q.ev_fork, 0));
+    }
     q.sort_w.run(d_wtns + p->sv.lo, s2);
     HIP_TRY(hipEventRecord(q.ev_sortw, s2));
     // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: on their
