@@ -1,4 +1,4 @@
-"""Stage timing of the C restatement on the host cores (debug helper)."""
+"""Stage timing of the C restatement on the host cores (debug helper of the oracle; test infrastructure)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
