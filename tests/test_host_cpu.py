@@ -34,6 +34,12 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(zk):
         zk.msm_g1(bytes(64), bytes(32))
     with pytest.raises(zk.ZkHipError):
         zk.Prover(golden_path("multiplier2", "circuit.zkey"))
+    with pytest.raises(zk.ZkHipError):
+        zk.fr_ntt(bytes(64), inverse=False)
+    with pytest.raises(zk.ZkHipError):
+        zk.fixed_base_g1(bn.g1_to_bytes(bn.G1.gen), [1, 2, 3])
+    with pytest.raises(zk.ZkHipError):
+        zk.synth_chain_g1(4, bn.g1_to_bytes(bn.G1.gen), bn.g1_to_bytes(bn.G1.gen))
 
 
 @pytest.mark.parametrize("name", CIRCUITS)
