@@ -139,6 +139,34 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
 }
 
+// Lane model of the merge / reduction kernels: one lane per G1 element; a lane PAIR per G2 element
+// (even lane = real components, odd lane = imaginary components, curve29.hpp Fq2s) — half the
+// registers per lane, twice the lanes, no spills.  Memory layout is the same either way.
+template <class F> struct LaneModel;
+template <> struct LaneModel<Fq> {
+    static constexpr uint32_t LPE = 1;      // lanes per element
+    typedef Fq29 R;
+    __device__ __forceinline__ static XYZZ<R> load(const G1XYZZ *p) { return load_xyzz(p); }
+    __device__ __forceinline__ static void store(G1XYZZ *p, const XYZZ<R> &v) { store_xyzz(p, v); }
+    __device__ __forceinline__ static void store256(G1XYZZ *p, const XYZZ<R> &v) { store_xyzz_mont256(p, v); }
+};
+template <> struct LaneModel<Fq2> {
+    static constexpr uint32_t LPE = 2;
+    typedef Fq2s R;
+    __device__ __forceinline__ static XYZZ<R> load(const G2XYZZ *p) {     // memory: x.a x.b y.a y.b zz.a zz.b zzz.a zzz.b
+        const Fq *c = reinterpret_cast<const Fq *>(p) + (threadIdx.x & 1u);
+        return XYZZ<R>{R{Reg<Fq>::load(c)}, R{Reg<Fq>::load(c + 2)}, R{Reg<Fq>::load(c + 4)}, R{Reg<Fq>::load(c + 6)}};
+    }
+    __device__ __forceinline__ static void store(G2XYZZ *p, const XYZZ<R> &v) {
+        Fq *c = reinterpret_cast<Fq *>(p) + (threadIdx.x & 1u);
+        Reg<Fq>::store(c, v.x.v); Reg<Fq>::store(c + 2, v.y.v); Reg<Fq>::store(c + 4, v.zz.v); Reg<Fq>::store(c + 6, v.zzz.v);
+    }
+    __device__ __forceinline__ static void store256(G2XYZZ *p, const XYZZ<R> &v) {
+        Fq *c = reinterpret_cast<Fq *>(p) + (threadIdx.x & 1u);
+        Reg<Fq>::store256(c, v.x.v); Reg<Fq>::store256(c + 2, v.y.v); Reg<Fq>::store256(c + 4, v.zz.v); Reg<Fq>::store256(c + 6, v.zzz.v);
+    }
+};
+
 // ---------------------------------------------------------------- digits + two-level LDS counting sort
 // Signed c-bit digits d in [-2^(c-1), 2^(c-1) - 1] (a window value >= 2^(c-1) becomes negative
 // and carries into the next window; +2^(c-1) never occurs).  Every non-zero digit becomes one
@@ -608,17 +636,22 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2XYZZ *buckets, const
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_pair(XYZZ<F> *buckets, const XYZZ<F> *part, uint32_t *key, const uint32_t *flag,
                                                         uint32_t nlanes) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    typedef LaneModel<F> LM;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt / LM::LPE;
     if (t + 1 >= nlanes) return;
     const uint32_t kt = key[2 * (uint64_t)t + 1], kh = key[2 * (uint64_t)t + 2];
     if (kt == SLOT_EMPTY || kt != kh) return;
     if (!(flag[2 * (uint64_t)t + 2] & FLAG_ENDS)) return;       // continues further: generic levels
-    typedef REGF FR;
-    XYZZ<FR> a = load_xyzz(part + 2 * (uint64_t)t + 1);
-    add(a, load_xyzz(part + 2 * (uint64_t)t + 2));
-    store_xyzz(buckets + kt, a);
-    key[2 * (uint64_t)t + 1] = SLOT_EMPTY;
-    key[2 * (uint64_t)t + 2] = SLOT_EMPTY;
+    XYZZ<typename LM::R> a = LM::load(part + 2 * (uint64_t)t + 1);
+    add(a, LM::load(part + 2 * (uint64_t)t + 2));
+    LM::store(buckets + kt, a);
+    // (both lanes of a G2 pair have read the keys before either of them retires the slots: the pair
+    // is in one wave and the loads above precede these stores in program order)
+    if (gt % LM::LPE == 0) {
+        key[2 * (uint64_t)t + 1] = SLOT_EMPTY;
+        key[2 * (uint64_t)t + 2] = SLOT_EMPTY;
+    }
 }
 
 // Levels >= 2: the same chunked segmented sum over a bucket-sorted slot list of XYZZ partials.
@@ -626,24 +659,26 @@ template <class F>
 __global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XYZZ<F> *in_part, const uint32_t *in_key,
                                                       const uint32_t *in_flag, uint32_t nitems, XYZZ<F> *out_part,
                                                       uint32_t *out_key, uint32_t *out_flag, uint32_t nlanes) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt / LM::LPE;
     if (t >= nlanes) return;
     const uint32_t lo = t * ACC_CHUNK_N;
     const uint32_t hi = lo + ACC_CHUNK_N < nitems ? lo + ACC_CHUNK_N : nitems;
     uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
-    typedef REGF FR;
     uint32_t cur = SLOT_EMPTY, cflag = 0;
     XYZZ<FR> acc = XYZZ<FR>::inf();
     auto flush = [&]() {
         if (cur == SLOT_EMPTY) return;
         if ((cflag & FLAG_STARTS) && (cflag & FLAG_ENDS)) {
-            store_xyzz(buckets + cur, acc);
+            LM::store(buckets + cur, acc);
         } else if (!(cflag & FLAG_STARTS)) {         // continues a bucket begun in an earlier lane
-            store_xyzz(out_part + 2 * (uint64_t)t, acc);
+            LM::store(out_part + 2 * (uint64_t)t, acc);
             hkey = cur;
             hflag = cflag & FLAG_ENDS;
         } else {                                     // starts here, continues in a later lane
-            store_xyzz(out_part + 2 * (uint64_t)t + 1, acc);
+            LM::store(out_part + 2 * (uint64_t)t + 1, acc);
             tkey = cur;
             tflag = FLAG_STARTS;
         }
@@ -659,13 +694,15 @@ __global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XY
             acc = XYZZ<FR>::inf();
         }
         cflag = (cflag & FLAG_STARTS) | (fl & FLAG_ENDS);
-        add(acc, load_xyzz(in_part + i));
+        add(acc, LM::load(in_part + i));
     }
     flush();
-    out_key[2 * (uint64_t)t] = hkey;
-    out_flag[2 * (uint64_t)t] = hflag;
-    out_key[2 * (uint64_t)t + 1] = tkey;
-    out_flag[2 * (uint64_t)t + 1] = tflag;
+    if (gt % LM::LPE == 0) {
+        out_key[2 * (uint64_t)t] = hkey;
+        out_flag[2 * (uint64_t)t] = hflag;
+        out_key[2 * (uint64_t)t + 1] = tkey;
+        out_flag[2 * (uint64_t)t + 1] = tflag;
+    }
 }
 
 // Lane per chunk of REDUCE_CHUNK buckets: running sums give A = sum (j+1)*B[lo+j], T = sum B;
@@ -673,15 +710,16 @@ __global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XY
 template <class F>
 __global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, const XYZZ<F> *buckets, uint32_t nbuckets,
                                                            uint32_t chunk, uint32_t total_chunks) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LM::LPE;
     if (t >= total_chunks) return;
     const uint32_t chunks_per_window = nbuckets / chunk;
     const uint32_t cw = t % chunks_per_window;          // chunk index inside its window
     const XYZZ<F> *B = buckets + (uint64_t)t * chunk;   // windows (and MSMs) are laid back to back
-    typedef REGF FR;
     XYZZ<FR> run = XYZZ<FR>::inf(), sum = XYZZ<FR>::inf();
     for (int j = (int)chunk - 1; j >= 0; j--) {
-        add(run, load_xyzz(B + j));
+        add(run, LM::load(B + j));
         add(sum, run);
     }
     // sum += (cw*chunk) * run   — double-and-add, MSB first
@@ -694,37 +732,42 @@ __global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, con
         }
         add(sum, m);
     }
-    store_xyzz(scratch + t, sum);
+    LM::store(scratch + t, sum);
 }
 
 // Tree sum of `count` consecutive points per group, 2 inputs per lane + an LDS tree per workgroup:
 // grid (blocks_per_group, groups) -> one point per workgroup.  Launched repeatedly until one point
 // per (msm, window) is left; the last launch stores in the zkey's 2^256 Montgomery form.
-#define TREE_IN (2u * REDUCE_THREADS)
+template <class F>
+static constexpr uint32_t tree_in() { return 2u * REDUCE_THREADS / LaneModel<F>::LPE; }    // inputs per workgroup
+#define TREE_IN_MIN REDUCE_THREADS      // the smaller fan-in (G2): sizes the shared scratch formula
 template <class F>
 __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(XYZZ<F> *out, const XYZZ<F> *in, uint32_t count, uint32_t last) {
     extern __shared__ uint32_t lds_raw[];
-    typedef REGF FR;
-    XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    constexpr uint32_t NE = REDUCE_THREADS / LM::LPE;           // elements per workgroup pass
+    XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);      // one entry per lane (its component(s))
     const XYZZ<F> *X = in + (uint64_t)blockIdx.y * count;
-    const uint32_t i0 = blockIdx.x * TREE_IN + threadIdx.x, i1 = i0 + REDUCE_THREADS;
+    const uint32_t e = threadIdx.x / LM::LPE;
+    const uint32_t i0 = blockIdx.x * (2u * NE) + e, i1 = i0 + NE;
     XYZZ<FR> acc = XYZZ<FR>::inf();
-    if (i0 < count) acc = load_xyzz(X + i0);
-    if (i1 < count) add(acc, load_xyzz(X + i1));
+    if (i0 < count) acc = LM::load(X + i0);
+    if (i1 < count) add(acc, LM::load(X + i1));
     lds[threadIdx.x] = acc;
     __syncthreads();
-    for (uint32_t s = REDUCE_THREADS / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            XYZZ<FR> o = lds[threadIdx.x + s];
+    for (uint32_t s = NE / 2; s > 0; s >>= 1) {
+        if (e < s) {
+            XYZZ<FR> o = lds[threadIdx.x + s * LM::LPE];
             add(acc, o);
             lds[threadIdx.x] = acc;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (e == 0) {
         XYZZ<F> *dst = out + (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        if (last) store_xyzz_mont256(dst, acc);    // back to the zkey's 2^256 form
-        else store_xyzz(dst, acc);
+        if (last) LM::store256(dst, acc);    // back to the zkey's 2^256 form
+        else LM::store(dst, acc);
     }
 }
 
@@ -736,7 +779,7 @@ uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
     for (;;) {
         total += groups * cnt;
         if (cnt == 1) break;
-        cnt = (cnt + TREE_IN - 1) / TREE_IN;
+        cnt = (cnt + TREE_IN_MIN - 1) / TREE_IN_MIN;     // upper bound for both fan-ins
     }
     return total;
 }
@@ -923,14 +966,14 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
         s = tail.stream;
     }
     if (lanes > 1)
-        hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets,
+        hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256)), dim3(256), 0, s, buckets,
                            (const XYZZ<F> *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
     uint64_t off = 0;
     while (lanes > 1) {          // a single lane has no cut runs: everything it saw was complete
         uint64_t items = 2 * lanes;
         uint64_t nl = (items + ACC_CHUNK_N - 1) / ACC_CHUNK_N;
         uint64_t noff = off + items;
-        hipLaunchKernelGGL(k_msm_accum_ln<F>, dim3((uint32_t)((nl + 127) / 128)), dim3(128), 0, s, buckets, ws_part + off,
+        hipLaunchKernelGGL(k_msm_accum_ln<F>, dim3((uint32_t)((nl * LaneModel<F>::LPE + 127) / 128)), dim3(128), 0, s, buckets, ws_part + off,
                            ws_key + off, ws_flag + off, (uint32_t)items, ws_part + noff, ws_key + noff, ws_flag + noff, (uint32_t)nl);
         off = noff;
         lanes = nl;
@@ -954,8 +997,9 @@ static void launch_reduce(XYZZ<F> *window_sums, XYZZ<F> *scratch, const XYZZ<F> 
     uint32_t cnt = p.nbuckets / chunk;
     const uint32_t groups = n_msm * p.sets;
     uint32_t total_chunks = groups * cnt;
-    hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks + 127) / 128), dim3(128), 0, s, scratch, buckets, p.nbuckets, chunk, total_chunks);
-    const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename Reg<F>::type>);
+    hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks * LaneModel<F>::LPE + 127) / 128), dim3(128), 0, s, scratch, buckets, p.nbuckets, chunk, total_chunks);
+    const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename LaneModel<F>::R>);
+    const uint32_t TREE_IN = tree_in<F>();
     XYZZ<F> *in = scratch;
     for (;;) {
         uint32_t blocks = (cnt + TREE_IN - 1) / TREE_IN;
