@@ -273,15 +273,8 @@ struct Fp29 {
         t.l[8] = (int32_t)(c + a.l[8] - (int64_t)k * P[8]);
         return t;    // limbs 0..7 in [0, 2^29)
     }
-    // exact: value == 0 (mod p).  A lazy value is k*p with |k| <= 16 or it is not zero, and
-    // k = value * p^-1 mod 2^29 is visible in the lowest limb alone (the others are multiples of 2^29):
-    // one multiply rejects all but 33 / 2^29 of the non-zero values.  The rest takes the exact path:
-    // after reduce_near_zero the value is in (-p, p), zero iff all limbs are.
-    ZK_HD bool is_zero() const {
-        const int32_t k = (int32_t)((0u - (uint32_t)l[0] * N0INV) << 3) >> 3;      // l0 * p^-1 mod 2^29, sign-extended
-        if (k > 16 || k < -16) return false;
-        return reduce_near_zero(*this).is_zero_raw();
-    }
+    // exact: value == 0 (mod p).  After reduce_near_zero the value is in (-p, p): zero iff all limbs are.
+    ZK_HD bool is_zero() const { return reduce_near_zero(*this).is_zero_raw(); }
 
     // canonical representative in [0, p), limbs 0..8 all non-negative
     ZK_HD static Fq29 canonical(const Fq29 &a) {

@@ -1,0 +1,21 @@
+"""VALU instruction budget of one proof from a rocprofv3 --pmc SQ_INSTS_VALU run (ZKHIP_SERIAL=1 recommended).
+    python tools/instr_budget.py <dir> [proofs_profiled=2]"""
+import csv, glob, collections, sys
+d = sys.argv[1]
+nproofs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+agg = collections.defaultdict(float); cnt = collections.Counter(); dur = collections.defaultdict(float)
+for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != 'SQ_INSTS_VALU':
+            continue
+        n = r['Kernel_Name'].replace('void zk::', '').replace('zk::', '')
+        key = n.split('(')[0]
+        if 'Fp2T' in n:
+            key += ' [G2]'
+        agg[key] += float(r['Counter_Value']); cnt[key] += 1
+skip = ('precomp', 'chain', 'build_tables', 'fq_to_internal', 'fr_convert', 'csr', 'fixed_base')
+rows = [(v / nproofs, k, cnt[k] / nproofs) for k, v in agg.items() if not any(x in k for x in skip)]
+tot = sum(v for v, _, _ in rows)
+for v, k, c in sorted(rows, reverse=True)[:18]:
+    print("%-52s %5.1f launches  %8.3f G instr  %5.1f%%" % (k[:52], c, v / 1e9, 100 * v / tot))
+print("total per proof %.2f G wave-level VALU instructions" % (tot / 1e9))
