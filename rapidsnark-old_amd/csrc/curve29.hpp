@@ -153,6 +153,18 @@ struct Fq2s {
         const Fq29 a0 = from_even(x.v), a1 = from_odd(x.v), yo = other(y.v);
         return Fq2s{Fq29::mul_add2(a0, y.v, sel(odd(), a1, Fq29::neg_lazy(a1)), yo)};
     }
+    // An operand used in several products is exchanged once: Pre holds (a0, +-a1) of it, the other
+    // factor only needs its partner component.
+    struct Pre {
+        Fq29 a0, a1s;
+    };
+    static __device__ __forceinline__ Pre prepare(const Fq2s &x) {
+        const Fq29 a1 = from_odd(x.v);
+        return Pre{from_even(x.v), sel(odd(), a1, Fq29::neg_lazy(a1))};
+    }
+    static __device__ __forceinline__ Fq2s mul(const Pre &x, const Fq2s &y) {
+        return Fq2s{Fq29::mul_add2(x.a0, y.v, x.a1s, other(y.v))};
+    }
     // re = (a0 + a1)(a0 - a1), im = 2 a0 a1 = (a0 + a0) * a1:  u = a0 + partner, w = own - (even ? a1 : 0)
     static __device__ __forceinline__ Fq2s sqr(const Fq2s &x) {
         const Fq29 a0 = from_even(x.v), xo = other(x.v);
@@ -183,11 +195,13 @@ __device__ __forceinline__ void madd(XYZZ<Fq2s> &acc, const Affine<Fq2s> &p) {
         return;
     }
     F PP = F::sqr(P);
-    acc.zz = F::mul(acc.zz, PP);
-    F Q = F::mul(acc.x, PP);
-    F PPP = F::mul(P, PP);
-    acc.zzz = F::mul(acc.zzz, PPP);
-    F T2 = F::mul(acc.y, PPP);
+    const F::Pre pp = F::prepare(PP);             // PP and PPP enter three and two products: exchanged once each
+    acc.zz = F::mul(pp, acc.zz);
+    F Q = F::mul(pp, acc.x);
+    F PPP = F::mul(pp, P);
+    const F::Pre ppp = F::prepare(PPP);
+    acc.zzz = F::mul(ppp, acc.zzz);
+    F T2 = F::mul(ppp, acc.y);
     F R2 = F::sqr(R);
 #pragma unroll
     for (int i = 0; i < 9; i++) acc.x.v.l[i] = R2.v.l[i] - PPP.v.l[i] - (Q.v.l[i] << 1);
