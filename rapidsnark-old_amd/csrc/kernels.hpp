@@ -30,15 +30,21 @@ void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor
 void launch_exclusive_scan_u32(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s);
 
 // ---------------------------------------------------------------- ntt.hip
+// A butterfly twiddle as the NTT kernel consumes it: the nine 29-bit limbs of the canonical value
+// (2^261 Montgomery form), padded to 48 bytes so that an entry is three aligned 16-byte loads and
+// needs no word->limb conversion per butterfly.
+struct TwEntry {
+    uint32_t l[12];
+};
 struct NttTables {
     uint32_t logn;       // domain size 2^logn
-    const Fr *fwd;       // w_n^k,  k < n/2   (all tables: canonical words of the 2^261 Montgomery form)
-    const Fr *inv;       // w_n^-k, k < n/2
-    const Fr *coset;     // n^-1 * w_2n^brev(p) for position p < n  (bit-reversed order)
+    const TwEntry *fwd;  // w_n^k,  k < n/2
+    const TwEntry *inv;  // w_n^-k, k < n/2
+    const Fr *coset;     // n^-1 * w_2n^brev(p) for position p < n  (bit-reversed order; canonical words of the 2^261 form)
     const Fr *ninv;      // single element n^-1 (Montgomery)
 };
 // fill the tables (device memory already allocated: n/2, n/2, n, 1 elements)
-void launch_ntt_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s);
+void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s);
 // Batched in-place transforms of `batch` polynomials laid out at data + k*stride_elems.
 //  dif_inverse: natural -> bit-reversed, inverse twiddles, NO scaling
 //  dit_forward: bit-reversed -> natural, forward twiddles

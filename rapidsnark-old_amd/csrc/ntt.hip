@@ -56,10 +56,26 @@ __device__ __forceinline__ void lds_put(int32_t *lds, uint32_t N, uint32_t e, co
 // w = tw[j << (logn-1-b)] = w_n^(j*n/2^(b+1)), j = low b bits of the element index.
 // premul (optional): element i is multiplied by premul[i] as it is loaded.
 // Lazy ranges (field29.hpp): a DIT value grows by < 1.2p per stage (11 stages: < 15p, and only
-// ever meets a canonical twiddle in a product); the DIF sum u+v would double per stage, so it is
-// pulled back to (-p/2, p/2) each stage.  Stores canonicalise.
+// ever meets a canonical twiddle in a product); the DIF sum u+v doubles per stage, so it is
+// pulled back to (-p/2, p/2) every third stage.  Stores canonicalise.
+__device__ __forceinline__ Fr29 load_tw(const TwEntry *e) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(e);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    Fr29 w;
+    w.l[0] = (int32_t)a.x; w.l[1] = (int32_t)a.y; w.l[2] = (int32_t)a.z; w.l[3] = (int32_t)a.w;
+    w.l[4] = (int32_t)b.x; w.l[5] = (int32_t)b.y; w.l[6] = (int32_t)b.z; w.l[7] = (int32_t)b.w;
+    w.l[8] = (int32_t)c.x;
+    return w;
+}
+__device__ __forceinline__ void store_tw(TwEntry *e, const Fr29 &v) {       // v canonical: limbs in [0, 2^29)
+    uint4 *q = reinterpret_cast<uint4 *>(e);
+    q[0] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
+    q[1] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
+    q[2] = make_uint4((uint32_t)v.l[8], 0u, 0u, 0u);
+}
+
 template <bool DIF>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t stride_elems, const Fr *tw, const Fr *premul,
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t stride_elems, const TwEntry *tw, const Fr *premul,
                                                           uint32_t logn, uint32_t lo, uint32_t t, uint32_t q) {
     extern __shared__ int32_t lds[];
     const uint32_t T = t + q, N = 1u << T;
@@ -96,9 +112,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t str
                 s0 = Fr29::add(u, v);
                 s1 = Fr29::sub(u, v);
             } else {
-                Fr29 w = Fr29::load(load_el(tw + (j << tshift)));
+                Fr29 w = load_tw(tw + (j << tshift));
                 if (DIF) {
-                    s0 = Fr29::reduce_near_zero(Fr29::add(u, v));
+                    // the sum doubles per stage: pull it back every third stage (< 8p in between,
+                    // well inside the (-13p, 13p) the 2^261 radix tolerates; the stores canonicalise)
+                    s0 = Fr29::add(u, v);
+                    if (s % 3u == 2u) s0 = Fr29::reduce_near_zero(s0);
                     s1 = Fr29::mul(Fr29::sub(u, v), w);
                 } else {
                     v = Fr29::mul(v, w);
@@ -147,7 +166,7 @@ static PassPlan plan_passes(uint32_t logn) {
 }
 
 template <bool DIF>
-static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const Fr *tw, const Fr *premul, uint32_t logn,
+static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *tw, const Fr *premul, uint32_t logn,
                      uint32_t lo, uint32_t t, uint32_t q, hipStream_t s) {
     uint32_t T = t + q;
     uint32_t tiles = 1u << (logn - T);
@@ -290,7 +309,7 @@ __device__ Fr fr_root_of_unity(uint32_t k) {
     return w;
 }
 
-__global__ __launch_bounds__(256) void k_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv_out, uint32_t logn) {
+__global__ __launch_bounds__(256) void k_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv_out, uint32_t logn) {
     const uint64_t n = 1ull << logn;
     __shared__ Fr s_wn, s_wninv, s_w2n, s_ninv;
     if (threadIdx.x == 0) {
@@ -309,8 +328,8 @@ __global__ __launch_bounds__(256) void k_build_tables(Fr *fwd, Fr *inv, Fr *cose
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
         if (i < (n >> 1) || n == 1) {
             if (n > 1) {
-                store_el(fwd + i, Fr29::store(Fr29::from_mont256(fr_pow(s_wn, i))));
-                store_el(inv + i, Fr29::store(Fr29::from_mont256(fr_pow(s_wninv, i))));
+                store_tw(fwd + i, Fr29::canonical(Fr29::from_mont256(fr_pow(s_wn, i))));
+                store_tw(inv + i, Fr29::canonical(Fr29::from_mont256(fr_pow(s_wninv, i))));
             }
         }
         uint32_t k = brev((uint32_t)i, logn);
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(256) void k_build_tables(Fr *fwd, Fr *inv, Fr *cose
     }
 }
 
-void launch_ntt_build_tables(Fr *fwd, Fr *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s) {
+void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s) {
     uint64_t n = 1ull << logn;
     uint64_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;

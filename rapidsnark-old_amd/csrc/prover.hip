@@ -115,7 +115,8 @@ struct zk_prover {
     // resident data
     DevBuf<uint32_t> csr_rowptr, csr_col;
     DevBuf<Fr> csr_val;
-    DevBuf<Fr> tw_fwd, tw_inv, tw_coset, tw_ninv;
+    DevBuf<TwEntry> tw_fwd, tw_inv;
+    DevBuf<Fr> tw_coset, tw_ninv;
     Slice sv, sh;              // this shard's slice of witness indices / domain indices
     uint32_t c_idx_min = 0;    // C-MSM: local witness index >= c_idx_min maps to pointsC[idx - c_idx_min]
     bool precomp = false;      // window-precomputed tables (ZK_FLAG_PRECOMP): tables hold W rows of n points
@@ -727,7 +728,8 @@ static void mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n
 }
 
 struct Tables {
-    DevBuf<Fr> fwd, inv, coset, ninv;
+    DevBuf<TwEntry> fwd, inv;
+    DevBuf<Fr> coset, ninv;
     NttTables t;
     void build(uint32_t logn) {
         uint64_t n = 1ull << logn;
