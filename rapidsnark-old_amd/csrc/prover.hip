@@ -165,6 +165,9 @@ struct zk_prover {
     uint32_t accum_launches = 0;
 
     ~zk_prover() {
+        // proofs may still be in flight (submitted, never collected): drain before anything is released
+        for (hipStream_t st : {stream, stream2, stream3, stream4, stream_fin})
+            if (st) (void)hipStreamSynchronize(st);
         if (stream_fin) (void)hipStreamDestroy(stream_fin);
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4);
