@@ -105,6 +105,17 @@ int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uin
  * zk_prove_dev_submit (r32/s32 ignored) + zk_prove_msm_collect, which hands back this shard's
  * partial sums for zk_prove_finish. */
 int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32);
+/* The same with the witness in HOST memory — the reference's own contract, Prover::prove(FrElement
+ * *wtns) (src/groth16.hpp:101, call sites src/main_prover.cpp:74-75, src/fullprover.cpp:155).  The
+ * upload runs on a stream of its own into a per-proof HBM buffer, so the witness of proof k+1 goes
+ * up while proof k computes.  A pageable buffer is copied to pinned staging before this returns
+ * (the caller may reuse it at once); a buffer from zk_host_alloc (or otherwise page-locked) is read
+ * by the DMA engine directly and must stay untouched until the proof has been collected. */
+int zk_prove_submit(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32);
+/* Page-locked host memory for witnesses (what a witness generator or a .wtns reader should fill:
+ * src/fullprover.cpp:139-145 reads the file into a malloc'ed image, src/binfile_utils.cpp:28-33). */
+int zk_host_alloc(void **out, size_t bytes);
+void zk_host_free(void *ptr);
 int zk_prove_collect(zk_prover *p, zk_proof *out);
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);
 
@@ -126,7 +137,7 @@ int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta
  * the *_L1_KERNEL entries bracket exactly one launch of the level-1 accumulation kernel. */
 enum {
     ZK_T_SPMV = 0, ZK_T_NTT, ZK_T_DIGITS_SORT, ZK_T_MSM_H, ZK_T_JOIN_WAIT, ZK_T_MSM_REDUCE,
-    ZK_T_TOTAL_DEVICE, ZK_T_G1_L1_KERNEL, ZK_T_G2_L1_KERNEL, ZK_T_COUNT
+    ZK_T_TOTAL_DEVICE, ZK_T_G1_L1_KERNEL, ZK_T_G2_L1_KERNEL, ZK_T_WTNS_H2D, ZK_T_COUNT
 };
 int zk_prover_timings(zk_prover *p, double *ms, uint32_t n);
 

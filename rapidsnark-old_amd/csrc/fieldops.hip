@@ -1,5 +1,6 @@
 // Pointwise Fr/Fq kernels and the sparse A.w / B.w accumulation (src/groth16.cpp:56-96).
 #include "kernels.hpp"
+#include "hipcheck.hpp"
 #include "field29.hpp"
 
 namespace zk {
@@ -36,9 +37,11 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256 *
 
 void launch_fr_mul_vec(Fr *out, const Fr *a, const Fr *b, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_mul_vec<Fr>, dim3(grid_for(n, 256)), dim3(256), 0, s, out, a, b, n);
+    ZK_LAUNCH_OK("fr_mul_vec");
 }
 void launch_fq_mul_vec(Fq *out, const Fq *a, const Fq *b, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_mul_vec<Fq>, dim3(grid_for(n, 256)), dim3(256), 0, s, out, a, b, n);
+    ZK_LAUNCH_OK("fq_mul_vec");
 }
 
 // One lane per domain row i: a[i] = sum_A coef*w[s], b[i] = sum_B coef*w[s], c[i] = a[i]*b[i].
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev cs
 
 void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_spmv_abc, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, csr, wtns, n);
+    ZK_LAUNCH_OK("spmv_abc");
 }
 
 // ---- CSR build on the device (the reference has no such step: it walks the records under 1024
@@ -111,13 +115,14 @@ __global__ __launch_bounds__(256) void k_csr_fill(uint32_t *col, Fr *val, uint32
 void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor, uint32_t *err, const uint8_t *records,
                       uint64_t nCoefs, uint32_t n, uint32_t nVars, hipStream_t s) {
     const uint32_t rows = 2 * n;
-    (void)hipMemsetAsync(cursor, 0, (size_t)rows * 4, s);
-    (void)hipMemsetAsync(err, 0, 4, s);
+    ZK_HIP(hipMemsetAsync(cursor, 0, (size_t)rows * 4, s));
+    ZK_HIP(hipMemsetAsync(err, 0, 4, s));
     const uint32_t g = grid_for(nCoefs ? nCoefs : 1, 256, 256 * 16);
     hipLaunchKernelGGL(k_csr_count, dim3(g), dim3(256), 0, s, cursor, err, (const uint32_t *)records, nCoefs, n, nVars);
     launch_exclusive_scan_u32(rowptr, cursor, rows, s);
-    (void)hipMemcpyAsync(cursor, rowptr, (size_t)rows * 4, hipMemcpyDeviceToDevice, s);
+    ZK_HIP(hipMemcpyAsync(cursor, rowptr, (size_t)rows * 4, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, col, val, cursor, (const uint32_t *)records, nCoefs, n, nVars);
+    ZK_LAUNCH_OK("csr build");
 }
 
 }   // namespace zk

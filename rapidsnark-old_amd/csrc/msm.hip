@@ -18,6 +18,7 @@
 // input is accepted like the reference's raw-byte interface.
 #include <stdlib.h>
 #include "kernels.hpp"
+#include "hipcheck.hpp"
 #include "field29.hpp"
 #include "curve29.hpp"
 #include <string.h>
@@ -137,6 +138,7 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
+    ZK_LAUNCH_OK("fq_to_internal");
 }
 
 // Lane model of the merge / reduction kernels: one lane per G1 element; a lane PAIR per G2 element
@@ -830,9 +832,9 @@ static inline size_t bin_scatter_lds_bytes() { return (size_t)(2 * BIN_MAX + 2 *
 static void sort_lds_attr() {
     static bool attr_set = false;
     if (attr_set) return;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
-    (void)hipFuncSetAttribute((const void *)k_bin_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_bin_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ZK_HIP(hipFuncSetAttribute((const void *)k_bin_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
 }
 
@@ -859,6 +861,7 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
     hipLaunchKernelGGL(k_bin_scatter_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
                        (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
     hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb, slices);
+    ZK_LAUNCH_OK("msm sort");
 }
 
 // ---------------------------------------------------------------- window pre-computation
@@ -910,6 +913,7 @@ static void precomp_table(Affine<F> *table, XYZZ<F> *tmp, F *pref, uint64_t n, M
     hipLaunchKernelGGL(k_precomp_walk<F>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, tmp, (const Affine<F> *)table, n, p.c, p.W);
     const uint64_t total = (uint64_t)(p.W - 1) * n, segs = (total + 63) / 64;
     hipLaunchKernelGGL(k_precomp_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, table + n, (const XYZZ<F> *)tmp, pref, total);
+    ZK_LAUNCH_OK("window pre-computation");
 }
 void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq>(table, tmp, pref, n, p, s); }
 void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq2>(table, tmp, pref, n, p, s); }
@@ -941,9 +945,9 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
                          XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
-    (void)hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s);
+    ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s));
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
-    if (ev) (void)hipEventRecord(ev[0], s);           // tight bracket around the level-1 kernel (roofline timing)
+    if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
         static const bool split = !(getenv("ZKHIP_G2_SPLIT") && atoi(getenv("ZKHIP_G2_SPLIT")) == 0);   // tuning aid
         if (split)
@@ -959,10 +963,10 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
                            points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
                            accum_chunk_for(max_entries ? max_entries : 1));
     }
-    if (ev) (void)hipEventRecord(ev[1], s);
+    if (ev) ZK_HIP(hipEventRecord(ev[1], s));
     if (tail.stream && tail.stream != s) {            // partial merges continue on the caller's follow-up stream
-        (void)hipEventRecord(tail.l1_done, s);
-        (void)hipStreamWaitEvent(tail.stream, tail.l1_done, 0);
+        ZK_HIP(hipEventRecord(tail.l1_done, s));
+        ZK_HIP(hipStreamWaitEvent(tail.stream, tail.l1_done, 0));
         s = tail.stream;
     }
     if (lanes > 1)
@@ -978,6 +982,7 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
         off = noff;
         lanes = nl;
     }
+    ZK_LAUNCH_OK("msm bucket accumulation");
 }
 
 void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
@@ -1010,6 +1015,7 @@ static void launch_reduce(XYZZ<F> *window_sums, XYZZ<F> *scratch, const XYZZ<F> 
         in = out;
         cnt = blocks;
     }
+    ZK_LAUNCH_OK("msm bucket reduction");
 }
 void launch_msm_reduce_g1(G1XYZZ *ws, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     launch_reduce<Fq>(ws, scratch, buckets, n_msm, p, s);

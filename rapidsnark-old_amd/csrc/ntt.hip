@@ -16,6 +16,7 @@
 //     (72 KiB per 2048-element tile); the coset*1/n table is applied as the first DIT pass loads.
 // The butterflies are Montgomery-multiply bound (VALU), see DESIGN.md.
 #include "kernels.hpp"
+#include "hipcheck.hpp"
 #include "field29.hpp"
 
 namespace zk {
@@ -173,11 +174,12 @@ static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *t
     size_t shmem = (size_t)36 << T;     // 9 limb planes; 72 KiB at T = 11 (opt-in above 64 KiB)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_ntt_pass<DIF>, dim3(tiles, batch), dim3(NTT_THREADS), shmem, s, data, stride, tw, premul, logn, lo, t, q);
+    ZK_LAUNCH_OK("ntt pass");
 }
 
 void launch_ntt_dif_inverse(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s) {
@@ -207,6 +209,7 @@ void launch_fr_scale_by_table(Fr *data, uint64_t stride, uint32_t batch, const F
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_scale_table, dim3((uint32_t)g, batch), dim3(256), 0, s, data, stride, table, n);
+    ZK_LAUNCH_OK("scale by table");
 }
 
 __global__ __launch_bounds__(256) void k_scale_const(Fr *x, const Fr *k, uint64_t n) {
@@ -219,6 +222,7 @@ void launch_fr_scale_const(Fr *data, const Fr *k, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_scale_const, dim3((uint32_t)g), dim3(256), 0, s, data, k, n);
+    ZK_LAUNCH_OK("scale");
 }
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -240,6 +244,7 @@ void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_bitrev, dim3((uint32_t)g), dim3(256), 0, s, data, logn);
+    ZK_LAUNCH_OK("bit reversal");
 }
 
 // h[i] = fromMontgomery(a[i]*b[i] - c[i])  (src/groth16.cpp:158-163): standard-form MSM scalars
@@ -254,6 +259,7 @@ void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, h
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_abc_to_h, dim3((uint32_t)g), dim3(256), 0, s, h, a, b, c, n);
+    ZK_LAUNCH_OK("abc_to_h");
 }
 
 // x*2^256 (the reference's Montgomery form) <-> x*2^261 (this library's internal form), in place
@@ -275,12 +281,14 @@ void launch_fr_to_internal(Fr *x, uint64_t n, int times, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 1, times);
+    ZK_LAUNCH_OK("fr_to_internal");
 }
 void launch_fr_from_internal(Fr *x, uint64_t n, hipStream_t s) {
     if (!n) return;
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 0, 1);
+    ZK_LAUNCH_OK("fr_from_internal");
 }
 
 // ------------------------------------------------------------------ twiddle tables
@@ -343,6 +351,7 @@ void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, ui
     uint64_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_build_tables, dim3((uint32_t)g), dim3(256), 0, s, fwd, inv, coset, ninv, logn);
+    ZK_LAUNCH_OK("twiddle tables");
 }
 
 }   // namespace zk

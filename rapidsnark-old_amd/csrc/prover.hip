@@ -21,21 +21,14 @@
 
 #include "../../include/zkhip.h"
 #include "common.hpp"
+#include "hipcheck.hpp"
 #include "kernels.hpp"
 
 using namespace zk;
 
 namespace {
 
-struct HipError {
-    std::string msg;
-};
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) throw HipError{std::string(#expr) + ": " + hipGetErrorString(_e)};   \
-    } while (0)
+#define HIP_TRY(expr) ZK_HIP(expr)
 
 template <class T>
 struct DevBuf {
@@ -83,6 +76,10 @@ struct SortBufs {
     void alloc(uint64_t n_, uint32_t window_bits, bool precomp = false) {
         n = n_;
         plan = make_msm_plan(n ? n : 1, window_bits, precomp);
+        // sort entries are 32-bit (bit 31 = digit sign): positions n*W and, with window-precomputed
+        // tables, table rows j*n + i must stay below 2^32 / 2^31
+        if ((n ? n : 1) * plan.W >= (1ull << 32)) throw std::invalid_argument("MSM too large: n * windows >= 2^32 sort entries");
+        if ((n ? n : 1) * (precomp ? plan.W : 1) >= (1ull << 31)) throw std::invalid_argument("MSM too large: table rows >= 2^31");
         MsmSortSizes z = msm_sort_sizes(n, plan);
         lo.alloc(z.lo_u16);
         counts.alloc(z.counts_u32);
@@ -124,7 +121,7 @@ struct zk_prover {
     DevBuf<G2Affine> ptsB2;
 
     // per-proof workspace used on `stream` only (in-order across consecutive proofs)
-    DevBuf<Fr> wtns, abc, h;   // abc = a|b|c back to back
+    DevBuf<Fr> abc, h;         // abc = a|b|c back to back
     SortBufs sort_h;
     // Everything a proof's witness-side streams and its asynchronous follow-up kernels touch lives
     // in a ProofSlot; two slots let the front of proof k+1 (sort, SpMV, NTT: LDS/latency-bound)
@@ -145,14 +142,24 @@ struct zk_prover {
         bool have_events = false;
         uint8_t *w1 = nullptr, *w2 = nullptr;      // pinned host copies of the window sums
         size_t w1_bytes = 0, w2_bytes = 0;
+        // host-witness proofs (zk_prove / zk_prove_submit): the witness of THIS proof in HBM, and the
+        // pinned staging copy a pageable caller buffer goes through.  One per slot, so that proof
+        // k+1's upload runs (on its own stream) while proof k is still computing.
+        DevBuf<Fr> wtns_dev;
+        uint8_t *wtns_pin = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_h2d_start = nullptr;
         uint8_t r32[32], s32[32];
         bool have_r = false, have_s = false;
+        bool host_witness = false;
         ~ProofSlot() {
             for (auto &e : ev_l1) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_f3, ev_f4, ev_done}) if (e) (void)hipEventDestroy(e);
             if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
             if (w1) (void)hipHostFree(w1);
             if (w2) (void)hipHostFree(w2);
+            if (wtns_pin) (void)hipHostFree(wtns_pin);
+            if (ev_h2d) (void)hipEventDestroy(ev_h2d);
+            if (ev_h2d_start) (void)hipEventDestroy(ev_h2d_start);
         }
     };
     ProofSlot slot[2];
@@ -160,14 +167,16 @@ struct zk_prover {
     uint32_t wbits = 0;
     hipStream_t stream3 = nullptr, stream4 = nullptr;   // follow-up streams of stream2 / stream: partial merges + bucket reductions
     hipStream_t stream_fin = nullptr;                   // joins a proof's streams and copies its window sums to the host
+    hipStream_t stream_h2d = nullptr;                   // witness uploads of host-witness proofs
 
     double timings[ZK_T_COUNT] = {0};
     uint32_t accum_launches = 0;
 
     ~zk_prover() {
         // proofs may still be in flight (submitted, never collected): drain before anything is released
-        for (hipStream_t st : {stream, stream2, stream3, stream4, stream_fin})
+        for (hipStream_t st : {stream_h2d, stream, stream2, stream3, stream4, stream_fin})
             if (st) (void)hipStreamSynchronize(st);
+        if (stream_h2d) (void)hipStreamDestroy(stream_h2d);
         if (stream_fin) (void)hipStreamDestroy(stream_fin);
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4);
@@ -177,6 +186,12 @@ struct zk_prover {
 };
 
 namespace {
+
+void need_device_count() {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw std::runtime_error("no HIP device available (libzkhip has no CPU fallback)");
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -195,7 +210,7 @@ int guarded(Fn fn) {
         fn();
         return 0;
     } catch (const HipError &e) {
-        set_error("HIP failure: " + e.msg);
+        set_error(std::string("HIP failure: ") + e.what());
         return 2;
     } catch (const std::exception &e) {
         set_error(e.what());
@@ -261,9 +276,7 @@ struct PhaseClock {
 void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     if (!out || !z) throw std::invalid_argument("null argument");
     PhaseClock clk;
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (ndev <= 0) throw std::runtime_error("no HIP device available (libzkhip has no CPU fallback)");
+    need_device_count();
     std::unique_ptr<zk_prover> p(new zk_prover());
     int dev = (o && o->device >= 0) ? o->device : -1;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
@@ -281,7 +294,11 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->nCoefs = z->nCoefs;
     if (z->nVars == 0 || z->nPublic + 1 > z->nVars) throw std::invalid_argument("invalid nVars/nPublic");
     p->logn = ilog2_exact(z->domainSize);
-    if (p->logn > 28) throw std::invalid_argument("domainSize exceeds the 2-adicity of BN254 Fr (2^28)");
+    // the coset shift needs a root of order 2*domainSize and BN254 Fr has 2-adicity 28 (the reference's
+    // FFT<Fr>(2*domainSize), src/groth16.hpp:94, rejects larger domains the same way)
+    if (p->logn > 27) throw std::invalid_argument("domainSize exceeds 2^27: the coset needs a root of order 2*domainSize and BN254 Fr has 2-adicity 28");
+    // 32-bit index limits of the device data structures (all reachable on a 288 GB part)
+    if (z->nCoefs >= (1ull << 32)) throw std::invalid_argument("nCoefs >= 2^32 is not supported (32-bit CSR positions)");
     const uint64_t n = z->domainSize, nV = z->nVars, nC = nV - z->nPublic - 1;
     // section size checks (the reference does none; an undersized section would be an OOB read)
     if (z->coefs_bytes && z->coefs_bytes < 4 + z->nCoefs * 44) throw std::invalid_argument("zkey section 4 too small");
@@ -334,6 +351,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         }
     }
     HIP_TRY(hipStreamCreateWithFlags(&p->stream_fin, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream_h2d, hipStreamNonBlocking));
     p->wbits = wbits;
     hipStream_t s = p->stream;
     clk.lap("device + streams", s);
@@ -433,7 +451,6 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     }
 
     // --- workspace (slot 0 was allocated above; slot 1 appears with the first overlapped submit)
-    p->wtns.alloc(nV);
     p->abc.alloc(3 * n);
     p->h.alloc(n);
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
@@ -441,16 +458,55 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     *out = p.release();
 }
 
+// Witness of a host-witness proof -> the slot's HBM copy, on the upload stream.  A caller buffer in
+// pinned memory (zk_host_alloc, or registered by the caller) is copied from directly; a pageable
+// one (the reference's contract: Prover::prove(FrElement *wtns), src/groth16.hpp:101) goes through
+// the slot's pinned staging buffer first (threaded memcpy), so that the H2D itself is always a
+// true asynchronous DMA that proof k's kernels hide.  Returns after the caller's buffer has been
+// read only in the pageable case; a pinned buffer must stay untouched until the proof is collected.
+static const Fr *upload_witness(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *h_wtns) {
+    const size_t bytes = (size_t)p->nVars * 32;
+    if (!q.wtns_dev.p) q.wtns_dev.alloc(p->nVars);
+    if (!q.ev_h2d) {
+        HIP_TRY(hipEventCreateWithFlags(&q.ev_h2d, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&q.ev_h2d_start));
+    }
+    hipPointerAttribute_t attr;
+    bool pinned = hipPointerGetAttributes(&attr, h_wtns) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();                       // an unregistered pointer is reported as an error: not one
+    const uint8_t *src = h_wtns;
+    if (!pinned) {
+        if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes, hipHostMallocDefault));
+        const size_t nt = bytes >= ((size_t)8 << 20) ? 4 : 1, per = (bytes / nt + 63) & ~(size_t)63;
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) {
+            const size_t lo = t * per, hi = lo + per < bytes ? lo + per : bytes;
+            if (lo < hi) th.emplace_back([=, &q] { memcpy(q.wtns_pin + lo, h_wtns + lo, hi - lo); });
+        }
+        memcpy(q.wtns_pin, h_wtns, per < bytes ? per : bytes);
+        for (auto &t : th) t.join();
+        src = q.wtns_pin;
+    }
+    const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
+    if (tm) HIP_TRY(hipEventRecord(q.ev_h2d_start, p->stream_h2d));
+    HIP_TRY(hipMemcpyAsync(q.wtns_dev.p, src, bytes, hipMemcpyHostToDevice, p->stream_h2d));
+    HIP_TRY(hipEventRecord(q.ev_h2d, p->stream_h2d));
+    if (tm) HIP_TRY(hipEventRecord(q.ev[12], p->stream_h2d));
+    return q.wtns_dev.p;
+}
+
 // Steps 1-10 of prove() (src/groth16.cpp:52-204), device part: everything is enqueued, nothing waits.
-// d_wtns: device pointer, nVars x 32 B, must stay valid until the proof is collected.
-// Caller holds p->mtx.
-static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, const uint8_t *s32) {
-    const bool staged = d_wtns == p->wtns.p;      // witness staged by an H2D copy on `stream` (zk_prove / zk_prove_msm)
+// Exactly one of d_wtns (device pointer, nVars x 32 B, must stay valid until the proof is collected)
+// and h_wtns (host pointer) is given.  Caller holds p->mtx.
+static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
     if (p->in_flight >= 2) throw std::invalid_argument("two proofs already in flight: collect one first");
     DeviceGuard g(p->device);
     const int si = (int)(p->next_submit & 1u);
     alloc_slot(p, si);
     zk_prover::ProofSlot &q = p->slot[si];
+    const bool staged = h_wtns != nullptr;
+    if (staged) d_wtns = upload_witness(p, q, h_wtns);
+    q.host_witness = staged;
     q.have_r = r32 != nullptr;
     q.have_s = s32 != nullptr;
     if (r32) memcpy(q.r32, r32, 32);
@@ -477,8 +533,8 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, co
     // it runs ahead, so that proof k+1's witness MSMs follow proof k's directly instead of waiting
     // for proof k's stream-1 work (at 2^20 that wait left stream2 idle for a third of the period)
     if (staged) {
-        HIP_TRY(hipEventRecord(q.ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(s2, q.ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(s, q.ev_h2d, 0));
+        HIP_TRY(hipStreamWaitEvent(s2, q.ev_h2d, 0));
     }
     q.sort_w.run(d_wtns + p->sv.lo, s2);
     HIP_TRY(hipEventRecord(q.ev_sortw, s2));
@@ -546,6 +602,7 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *r32, co
     HIP_TRY(hipMemcpyAsync(q.w1, q.wsum_g1.p, q.w1_bytes, hipMemcpyDeviceToHost, sf));
     HIP_TRY(hipMemcpyAsync(q.w2, q.wsum_g2.p, q.w2_bytes, hipMemcpyDeviceToHost, sf));
     HIP_TRY(hipEventRecord(q.ev_done, sf));
+    HIP_TRY(hipGetLastError());          // nothing of the ~100 launches above may have been refused
     q.busy = true;
     p->next_submit++;
     p->in_flight++;
@@ -557,10 +614,13 @@ static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out)
     if (!p->in_flight) throw std::invalid_argument("no proof in flight");
     DeviceGuard g(p->device);
     zk_prover::ProofSlot &q = p->slot[p->next_collect & 1u];
+    const hipError_t done = hipEventSynchronize(q.ev_done);
+    // the slot is retired whatever happened (a failed proof must not wedge the queue), but only
+    // AFTER the wait: nobody may reuse its buffers while its kernels can still run
     p->next_collect++;
     p->in_flight--;
     q.busy = false;
-    HIP_TRY(hipEventSynchronize(q.ev_done));
+    HIP_TRY(done);
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
     if (tm) {
         float ms[7], g1 = 0, g2 = 0;
@@ -578,6 +638,9 @@ static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out)
         p->timings[ZK_T_TOTAL_DEVICE] = ms[6];
         p->timings[ZK_T_G1_L1_KERNEL] = g1;          // k_msm_accum_l1<Fq>  of MSM A, tight events
         p->timings[ZK_T_G2_L1_KERNEL] = g2;          // k_msm_accum_l1<Fq2> of MSM B2, tight events
+        float h2d = 0;
+        if (q.host_witness) HIP_TRY(hipEventElapsedTime(&h2d, q.ev_h2d_start, q.ev[12]));
+        p->timings[ZK_T_WTNS_H2D] = h2d;             // witness upload (own stream; 0 for device-witness proofs)
     }
     const uint32_t Ww = q.sort_w.plan.sets, Wh = p->sort_h.plan.sets;
     const uint32_t cw = q.sort_w.plan.c, ch = p->sort_h.plan.c;
@@ -596,22 +659,19 @@ static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out)
     return q;
 }
 
-void prove_msm(zk_prover *p, const Fr *d_wtns, zk_msm_sums *out) {
+// One synchronous proof.  The witness upload, the device work and the wait all happen under the
+// prover's mutex: concurrent callers are serialised proof by proof (Prover::prove is re-entrant
+// in the reference; here the per-proof buffers are the prover's).
+void prove_msm(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, zk_msm_sums *out) {
     std::lock_guard<std::mutex> lk(p->mtx);
     if (p->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
-    submit_locked(p, d_wtns, nullptr, nullptr);
+    submit_locked(p, d_wtns, h_wtns, nullptr, nullptr);
     collect_sums_locked(p, out);
 }
 
 void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
     if (zk_assemble(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, parts, nparts, r32, s32, out))
         throw std::runtime_error(get_error());
-}
-
-const Fr *stage_witness(zk_prover *p, const uint8_t *wtns) {
-    DeviceGuard g(p->device);
-    HIP_TRY(hipMemcpyAsync(p->wtns.p, wtns, (size_t)p->nVars * 32, hipMemcpyHostToDevice, p->stream));
-    return p->wtns.p;
 }
 
 }   // namespace
@@ -642,14 +702,14 @@ void zk_prover_destroy(zk_prover *p) {
 int zk_prove_msm_dev(zk_prover *p, const void *d_wtns, zk_msm_sums *partial) {
     return guarded([&] {
         if (!p || !d_wtns || !partial) throw std::invalid_argument("null argument");
-        prove_msm(p, (const Fr *)d_wtns, partial);
+        prove_msm(p, (const Fr *)d_wtns, nullptr, partial);
     });
 }
 
 int zk_prove_msm(zk_prover *p, const uint8_t *wtns, zk_msm_sums *partial) {
     return guarded([&] {
         if (!p || !wtns || !partial) throw std::invalid_argument("null argument");
-        prove_msm(p, stage_witness(p, wtns), partial);
+        prove_msm(p, nullptr, wtns, partial);
     });
 }
 
@@ -666,7 +726,7 @@ int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uin
         if (!p || !d_wtns || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove on a sharded prover: use zk_prove_msm + zk_prove_finish");
         zk_msm_sums sums;
-        prove_msm(p, (const Fr *)d_wtns, &sums);
+        prove_msm(p, (const Fr *)d_wtns, nullptr, &sums);
         prove_finish(p, &sums, 1, r32, s32, out);
     });
 }
@@ -676,7 +736,7 @@ int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_
         if (!p || !wtns || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove on a sharded prover: use zk_prove_msm + zk_prove_finish");
         zk_msm_sums sums;
-        prove_msm(p, stage_witness(p, wtns), &sums);
+        prove_msm(p, nullptr, wtns, &sums);
         prove_finish(p, &sums, 1, r32, s32, out);
     });
 }
@@ -685,8 +745,28 @@ int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, co
     return guarded([&] {
         if (!p || !d_wtns) throw std::invalid_argument("null argument");
         std::lock_guard<std::mutex> lk(p->mtx);
-        submit_locked(p, (const Fr *)d_wtns, r32, s32);
+        submit_locked(p, (const Fr *)d_wtns, nullptr, r32, s32);
     });
+}
+
+int zk_prove_submit(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32) {
+    return guarded([&] {
+        if (!p || !wtns) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        submit_locked(p, nullptr, wtns, r32, s32);
+    });
+}
+
+int zk_host_alloc(void **out, size_t bytes) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("null argument");
+        need_device_count();
+        HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    });
+}
+
+void zk_host_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial) {
@@ -727,11 +807,7 @@ int zk_prover_timings(zk_prover *p, double *ms, uint32_t n) {
 }   // extern "C"
 
 // ------------------------------------------------------------------ operator level
-static void need_device() {
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (ndev <= 0) throw std::runtime_error("no HIP device available (libzkhip has no CPU fallback)");
-}
+static void need_device() { need_device_count(); }
 
 template <class F>
 static void mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n, void (*launch)(F *, const F *, const F *, uint64_t, hipStream_t)) {

@@ -6,6 +6,7 @@
 // the chain with mixed adds.  Pass 2: XYZZ -> affine with one Fermat inversion per segment
 // (Montgomery's batch-inversion trick over the segment's ZZ*ZZZ products).
 #include "kernels.hpp"
+#include "hipcheck.hpp"
 
 namespace zk {
 
@@ -80,6 +81,7 @@ static void chain(Affine<F> *d_out, XYZZ<F> *d_tmp, F *d_pref, const Affine<F> &
     uint32_t blocks = (uint32_t)((segs + 63) / 64);
     hipLaunchKernelGGL(k_chain_walk<F>, dim3(blocks), dim3(64), 0, s, d_tmp, P0, Q, n);
     hipLaunchKernelGGL(k_chain_normalize<F>, dim3(blocks), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
+    ZK_LAUNCH_OK("synthetic chain");
 }
 
 // Batch fixed-base multiplication out[i] = k_i * B (a trapdoor-valid zkey is nothing but
@@ -105,6 +107,7 @@ static void fixed_base(Affine<F> *d_out, XYZZ<F> *d_tmp, F *d_pref, const Affine
     hipLaunchKernelGGL(k_fixed_base<F>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, d_tmp, B, d_scalars, n);
     uint64_t segs = (n + CHAIN_SEG - 1) / CHAIN_SEG;
     hipLaunchKernelGGL(k_chain_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
+    ZK_LAUNCH_OK("fixed-base batch");
 }
 void launch_fixed_base_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s) {
     fixed_base<Fq>(d_out, d_tmp, d_pref, B, d_scalars, n, s);

@@ -43,11 +43,11 @@ class zk_msm_sums(C.Structure):
 
 ZK_FLAG_TIMINGS = 1
 ZK_FLAG_PRECOMP = 2
-ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel"]
+ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel", "wtns_h2d"]
 
 # every symbol include/zkhip.h declares (tests check the library exports all of them)
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
-           "zk_prove_dev_submit", "zk_prove_collect", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
+           "zk_prove_dev_submit", "zk_prove_submit", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
            "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble"]
 
@@ -76,6 +76,10 @@ def load_library():
     lib.zk_prove.argtypes = [C.c_void_p, u8p, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_prove_dev.argtypes = [C.c_void_p, C.c_void_p, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_prove_dev_submit.argtypes = [C.c_void_p, C.c_void_p, u8p, u8p]
+    lib.zk_prove_submit.argtypes = [C.c_void_p, u8p, u8p, u8p]
+    lib.zk_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.zk_host_free.argtypes = [C.c_void_p]
+    lib.zk_host_free.restype = None
     lib.zk_prove_collect.argtypes = [C.c_void_p, C.POINTER(zk_proof)]
     lib.zk_prove_msm_collect.argtypes = [C.c_void_p, C.POINTER(zk_msm_sums)]
     lib.zk_prove_msm.argtypes = [C.c_void_p, u8p, C.POINTER(zk_msm_sums)]
@@ -124,6 +128,25 @@ def device_count():
     n = C.c_int(0)
     check(load_library().zk_device_count(C.byref(n)))
     return n.value
+
+
+class PinnedBuffer:
+    """Page-locked host memory from zk_host_alloc, exposed as a numpy uint8 array (`.array`).  A witness
+    placed here is uploaded by the DMA engine directly (zk_prove_submit does not stage it)."""
+
+    def __init__(self, nbytes):
+        self._ptr = C.c_void_p()
+        check(load_library().zk_host_alloc(C.byref(self._ptr), nbytes))
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array(C.cast(self._ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def free(self):
+        if self._ptr is not None and self._ptr.value:
+            self.array = None
+            load_library().zk_host_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    __del__ = free
 
 
 def _mul_vec(fn, a, b):

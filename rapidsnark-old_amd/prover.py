@@ -93,6 +93,16 @@ class Prover:
         (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
         L.check(self._lib.zk_prove_dev_submit(self._h, C.c_void_p(d_wtns_ptr), rp, sp))
 
+    def submit(self, wtns, r=None, s=None):
+        """Throughput mode with the witness in HOST memory (zk_prove_submit): .wtns path/bytes, raw value
+        bytes or a numpy uint8 array (e.g. a lib.PinnedBuffer's .array, which is then read in place and
+        must stay untouched until the matching collect())."""
+        a = wtns if isinstance(wtns, np.ndarray) else self._wtns_values(wtns)
+        if a.size != self.header.nVars * 32:
+            raise ValueError("witness size mismatch")
+        (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
+        L.check(self._lib.zk_prove_submit(self._h, C.c_void_p(a.ctypes.data), rp, sp))
+
     def collect(self):
         """-> proof bytes of the OLDEST submitted proof (zk_prove_collect)."""
         out = L.zk_proof()

@@ -14,6 +14,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_present():
+    try:
+        import rapidsnark_old_amd as zk
+        return zk.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a box without a GPU: the gpu-marked tests are skipped, not failed (the product
+    has no CPU fallback to fall back on)."""
+    gpu_items = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu_items or _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (libzkhip has no CPU fallback)")
+    for it in gpu_items:
+        it.add_marker(skip)
+
+
 def golden_path(*parts):
     return os.path.join(GOLDEN, *parts)
 

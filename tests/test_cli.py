@@ -68,3 +68,15 @@ def test_cli_random_rs_differs(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(pj.read_bytes())
     assert outs[0] != outs[1]
+
+
+@pytest.mark.gpu
+def test_parity_kit_self_check_on_our_prover():
+    """tools/refcheck/refcheck.py --ours: the kit that pins tests/golden/* against a real rapidsnark binary,
+    run against this repository's own `prover` (every fixture's proof.json / public.json byte-identical)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refcheck", "refcheck.py"), "--ours"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("IDENTICAL") == 10 and "PINNED" in res.stdout

@@ -112,3 +112,19 @@ def test_msm_g1_linearity_large(zk):
     r3 = bn.g1_from_bytes(zk.msm_g1(bases, ksum))
     assert G1.add(r1, r2) == r3
     assert G1.is_on_curve(r3) and r3 is not None
+
+
+def test_eip196_public_vectors_on_the_gpu(zk):
+    """zk_msm_g1 / zk_fixed_base_g1 / zk_g1_mul against the public EIP-196 precompile vectors (third-party
+    numbers, see tests/test_oracle_py.py): P + Q as a two-term MSM, k*B as a one-term MSM."""
+    from test_oracle_py import EIP196_2G, EIP196_ADD, EIP196_MUL
+    from oracle import bn254 as bn
+    one = bn.int_to_le32(1)
+    p, q, s = EIP196_ADD
+    assert zk.msm_g1(bn.g1_to_bytes(p) + bn.g1_to_bytes(q), one + one) == bn.g1_to_bytes(s)
+    b, k, r = EIP196_MUL
+    assert zk.msm_g1(bn.g1_to_bytes(b), bn.int_to_le32(k)) == bn.g1_to_bytes(r)
+    assert zk.fixed_base_g1(bn.g1_to_bytes(b), [k, 2]).tobytes() == bn.g1_to_bytes(r) + bn.g1_to_bytes(bn.G1.dbl(b))
+    g1 = bn.g1_to_bytes(bn.G1.gen)
+    assert zk.msm_g1(g1 + g1, one + one) == bn.g1_to_bytes(EIP196_2G)          # P = Q: the doubling branch of the mixed add
+    assert zk.g1_mul(g1, 2) == bn.g1_to_bytes(EIP196_2G)

@@ -136,3 +136,17 @@ def test_synthetic_family_definition(zk):
     s0, s1 = synth.weighted_sums(w)
     assert s0 == sum(vals) and s1 == sum(i * v for i, v in enumerate(vals))
     assert synth.g1_gen_bytes() == bn.g1_to_bytes(bn.G1.gen) and synth.g2_gen_bytes() == bn.g2_to_bytes(bn.G2.gen)
+
+
+def test_parity_kit_shim_serves_r_then_s(tmp_path):
+    """tools/refcheck: the LD_PRELOAD replacement of randombytes_buf hands out r on the first call and s
+    on the second, 31 bytes each, as src/groth16.cpp:216-217 consumes them."""
+    import subprocess
+    so = tmp_path / "librandshim.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O2", "-o", str(so), os.path.join(ROOT, "tools", "refcheck", "randombytes_shim.c")])
+    r, s = 0x1122334455, (1 << 247) + 99
+    code = ("import ctypes,os;l=ctypes.CDLL(%r);b=ctypes.create_string_buffer(31);"
+            "l.randombytes_buf(b,ctypes.c_size_t(31));print(b.raw.hex());l.randombytes_buf(b,ctypes.c_size_t(31));print(b.raw.hex())" % str(so))
+    env = dict(os.environ, ZKREF_R=r.to_bytes(32, "little").hex(), ZKREF_S=s.to_bytes(32, "little").hex())
+    out = subprocess.run(["python3", "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == [r.to_bytes(31, "little").hex(), s.to_bytes(31, "little").hex()]

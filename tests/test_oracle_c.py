@@ -87,3 +87,16 @@ def test_msm_random_mid_size_vs_dlog():
     sc = [rng.randrange(bn.R_MOD) for _ in range(n)]
     total = sum(k * (k0 + i * kq) for i, k in enumerate(sc)) % bn.R_MOD
     assert co.msm_g1(bases, pack(sc)) == co.g1_mul(bn.g1_to_bytes(G1.gen), total)
+
+
+def test_eip196_public_vectors_c():
+    """The C restatement against the public EIP-196 precompile vectors (see test_oracle_py.py)."""
+    from test_oracle_py import EIP196_2G, EIP196_ADD, EIP196_MUL
+    from oracle import bn254 as bn, c_oracle as co
+    g1 = bn.g1_to_bytes(bn.G1.gen)
+    assert co.g1_mul(g1, 2) == bn.g1_to_bytes(EIP196_2G)
+    b, k, r = EIP196_MUL
+    assert co.g1_mul(bn.g1_to_bytes(b), k) == bn.g1_to_bytes(r)
+    p, q, s = EIP196_ADD
+    one = bn.int_to_le32(1)
+    assert co.msm_g1(bn.g1_to_bytes(p) + bn.g1_to_bytes(q), one + one) == bn.g1_to_bytes(s)

@@ -82,3 +82,36 @@ def test_binfile_errors_follow_the_reference_texts():
         g.read_binfile(b"abcd" + bytes(8), b"zkey", 1)
     with pytest.raises(ValueError, match="Invalid version"):
         g.read_binfile(b"zkey" + (9).to_bytes(4, "little") + bytes(4), b"zkey", 1)
+
+
+# Public BN254 (alt_bn128) vectors that were NOT produced by this repository: the "chfast1" cases of the
+# Ethereum precompile test suites for EIP-196 (ecAdd 0x06 / ecMul 0x07) and the value of 2*G1 that
+# appears throughout the EIP-196 test corpus.  The reference holds no vectors of its own,
+# so these are the only third-party numbers the oracle's curve arithmetic can be pinned to.
+EIP196_2G = (0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3,
+             0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4)
+EIP196_ADD = ((0x18b18acfb4c2c30276db5411368e7185b311dd124691610c5d3b74034e093dc9,
+               0x063c909c4720840cb5134cb9f59fa749755796819658d32efc0d288198f37266),
+              (0x07c2b7f58a84bd6145f00c9c2bc0bb1a187f20ff2c92963a88019e7c6a014eed,
+               0x06614e20c147e940f2d70da3f74c9a17df361706a4485c742bd6788478fa17d7),
+              (0x2243525c5efd4b9c3d3c45ac0ca3fe4dd85e830a4ce6b65fa1eeaee202839703,
+               0x301d1d33be6da8e509df21cc35964723180eed7532537db9ae5e7d48f195c915))
+EIP196_MUL = ((0x2bd3e6d0f3b142924f5ca7b49ce5b9d54c4703d7ae5648e61d02268b1a0a9fb7,
+               0x21611ce0a6af85915e2f1d70300909ce2e49dfad4a4619c8390cae66cefdb204),
+              0x11138ce750fa15c2,
+              (0x070a8d6a982153cae4be29d434e8faef8a47b274a053f5a4ee2a6c9c13c31e5c,
+               0x031b8ce914eba3a9ffb989f9cdd5b0f01943074bf4f0f315690ec3cec6981afc))
+
+
+def test_eip196_public_vectors():
+    assert G1.dbl(G1.gen) == EIP196_2G == G1.add(G1.gen, G1.gen) == G1.mul(G1.gen, 2)
+    p, q, s = EIP196_ADD
+    assert G1.is_on_curve(p) and G1.is_on_curve(q) and G1.add(p, q) == s and G1.add(q, p) == s
+    b, k, r = EIP196_MUL
+    assert G1.is_on_curve(b) and G1.mul(b, k) == r
+    # EIP-197 generator of G2 (the constant the pairing precompile fixes): on the twist, order r
+    assert G2.gen == ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+                       11559732032986387107991004021392285783925812861821192530917403151452391805634),
+                      (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+                       4082367875863433681332203403145435568316851327593401208105741076214120093531))
+    assert G2.is_on_curve(G2.gen) and G2.mul(G2.gen, R_MOD) is None
