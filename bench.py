@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1 (default, single GPU): consecutive proofs overlap through zk_prove_dev_submit / zk_prove_collect "
                          "(two in flight); 0: strictly one proof at a time (zk_prove_dev)")
+    ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = 3 with host witnesses, 2 with resident ones; max 3)")
     ap.add_argument("--witness-in", choices=["host", "hbm"], default="host",
                     help="host (default): witnesses are pageable host arrays and every upload is timed (the reference's contract); "
                          "hbm: witnesses resident in HBM before the timed region")
@@ -68,6 +69,7 @@ def parse():
 
 def main():
     args = parse()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # six streams per prover (csrc/prover.hip); read when HIP initialises
     import torch
     import rapidsnark_old_amd as zk
     from rapidsnark_old_amd import synth
@@ -148,15 +150,23 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if pipelined:
-            # proof i+1 is enqueued (witness upload included) before proof i is collected: its upload,
-            # sort, SpMV and NTTs overlap proof i's reductions, D2H and host tail
-            submit(warmup)
-            for i in range(1, steps):
+            # up to `depth` proofs in flight: proof i+1 is enqueued (witness upload included) before proof
+            # i is collected, so its sort, SpMV and NTTs overlap proof i's reductions, D2H and host tail;
+            # with host witnesses a third proof hides the upload (a proof cannot start before its witness
+            # has arrived, and a slot is only free again after a collect)
+            depth = args.in_flight or (2 if in_hbm else 3)
+            flying = 0
+            for i in range(steps):
                 submit(warmup + i)
+                flying += 1
+                if flying == depth:
+                    collect()
+                    add_timings()
+                    flying -= 1
+            while flying:
                 collect()
                 add_timings()
-            collect()
-            add_timings()
+                flying -= 1
         else:
             for i in range(steps):
                 submit(warmup + i)
@@ -212,7 +222,7 @@ def main():
     # accumulation of MSM B2 (160 B per point).
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
               "log2n": k, "parallelism": "msm-point-shard x%d" % world, "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
-              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": 2 if pipelined else 1,
+              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or (2 if headline_hbm else 3)) if pipelined else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
     pts_per_launch = n / world

@@ -57,6 +57,10 @@ typedef struct zk_opts {
 } zk_opts;
 
 #define ZK_FLAG_TIMINGS 1u   /* record per-stage hipEvent timings (zk_prover_timings) */
+#define ZK_FLAG_PARTITIONED_CHAIN 4u   /* sharded provers only (shard_count 2, 4 or 8): the A.w/B.w rows and the six
+                              * transforms are PARTITIONED over the shards too (each holds the block of rows its H
+                              * table slice covers) instead of replicated; such provers are driven through
+                              * zk_multi_prove* (one process) or zk_shard_* (one process per GPU) */
 #define ZK_FLAG_PRECOMP 2u   /* window-precomputed point tables: W x the table memory in HBM and a longer
                               * zk_prover_create, ~19 % fewer point additions per proof (same results) */
 
@@ -98,19 +102,22 @@ int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uin
  * proves strictly one at a time (src/fullprover.cpp:96-97: one worker thread); on the GPU the
  * latency-bound front of proof k+1 (digit sort, A.w/B.w, NTTs) hides under the tail of proof k
  * (bucket reductions, D2H, host Horner + final assembly, src/groth16.cpp:219-251).
- * zk_prove_dev_submit enqueues all device work of one proof and returns; at most TWO proofs may
- * be in flight per prover.  zk_prove_collect blocks until the OLDEST submitted proof is complete
+ * zk_prove_dev_submit enqueues all device work of one proof and returns; at most ZK_MAX_IN_FLIGHT
+ * proofs may be in flight per prover (two keep the chip busy when witnesses are resident in HBM; the
+ * third hides the upload of a host witness, whose proof cannot start before the witness has arrived).  zk_prove_collect blocks until the OLDEST submitted proof is complete
  * and writes it.  d_wtns must stay valid (and unmodified) until its proof has been collected;
  * r32/s32 are copied at submit (NULL = random, drawn at collect).  On a sharded prover the pair is
  * zk_prove_dev_submit (r32/s32 ignored) + zk_prove_msm_collect, which hands back this shard's
  * partial sums for zk_prove_finish. */
+#define ZK_MAX_IN_FLIGHT 3
 int zk_prove_dev_submit(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uint8_t *s32);
 /* The same with the witness in HOST memory — the reference's own contract, Prover::prove(FrElement
  * *wtns) (src/groth16.hpp:101, call sites src/main_prover.cpp:74-75, src/fullprover.cpp:155).  The
  * upload runs on a stream of its own into a per-proof HBM buffer, so the witness of proof k+1 goes
- * up while proof k computes.  A pageable buffer is copied to pinned staging before this returns
- * (the caller may reuse it at once); a buffer from zk_host_alloc (or otherwise page-locked) is read
- * by the DMA engine directly and must stay untouched until the proof has been collected. */
+ * up while proof k computes, and the call itself returns at once: a pageable buffer is copied to
+ * pinned staging by a host function on that stream, a buffer from zk_host_alloc (or otherwise
+ * page-locked) is read by the DMA engine directly.  Either way `wtns` must stay valid and untouched
+ * until its proof has been collected (as for zk_prove_dev_submit). */
 int zk_prove_submit(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32);
 /* Page-locked host memory for witnesses (what a witness generator or a .wtns reader should fill:
  * src/fullprover.cpp:139-145 reads the file into a malloc'ed image, src/binfile_utils.cpp:28-33). */
@@ -125,6 +132,45 @@ int zk_prove_msm(zk_prover *p, const uint8_t *wtns, zk_msm_sums *partial);
 /* ... and steps 11-13 (src/groth16.cpp:209-253) over the partial sums of all shards (host, O(1)). */
 int zk_prove_finish(zk_prover *p, const zk_msm_sums *partials, uint32_t n_partials,
                     const uint8_t *r32, const uint8_t *s32, zk_proof *out);
+
+/* ---- one proof on several GPUs with the chain PARTITIONED too (north_star: "the five MSMs and the NTT
+ * partitioned across the 8 GPUs").  GPU g holds rows [g*n/G, (g+1)*n/G) of a = A.w, b = B.w, c, h (the
+ * slice its H table covers), runs the stages over the low log2(n/G) index bits of the six transforms
+ * (src/groth16.cpp:98-155) locally and meets the others only in the log2(G) top stages: one radix-G
+ * butterfly per block offset, for which each GPU receives 1/G of every block (all-to-all), computes,
+ * and returns the results (all-to-all) — 2 x (G-1)/G of a block per GPU and transform over xGMI.
+ *
+ * (a) All GPUs in ONE process — what the reference's CLI / server are (src/main_prover.cpp:57-75,
+ *     src/fullprover.cpp:154-159).  One shard prover per device inside; blocks exchanged by peer
+ *     writes, cross-device ordering by events; one host thread enqueues everything.  devices may name
+ *     the same device several times (all shards on one GPU: how the tests exercise this path on a
+ *     1-GPU box).  The chain is partitioned when n_devices is 2, 4 or 8 and domainSize >= n_devices^2
+ *     (ZKHIP_REPLICATED_CHAIN=1 in the environment keeps it replicated), otherwise replicated.
+ *     zk_multi_prove = Prover::prove; submit/collect as zk_prove_submit / zk_prove_collect. */
+typedef struct zk_multi_prover zk_multi_prover;
+int zk_multi_prover_create(zk_multi_prover **out, const zk_zkey_view *zkey, const int32_t *devices, uint32_t n_devices,
+                           const zk_opts *opts /* device, shard_* ignored */);
+void zk_multi_prover_destroy(zk_multi_prover *mp);
+int zk_multi_prove(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out);
+int zk_multi_prove_submit(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32);
+int zk_multi_prove_collect(zk_multi_prover *mp, zk_proof *out);
+int zk_multi_prover_info(zk_multi_prover *mp, uint32_t *n_shards, uint32_t *chain_partitioned);
+/* (b) One process per GPU (torch.distributed over RCCL): a prover created with shard_index/shard_count and
+ *     ZK_FLAG_PARTITIONED_CHAIN is driven step by step, and the CALLER moves the blocks between the steps
+ *     with four all_to_all per proof on two buffers it owns and registers here (3 polynomials x block_elems
+ *     x 32 bytes each; `abc` holds the three blocks, `xb` is the exchange buffer [poly][source GPU][chunk]):
+ *         zk_shard_begin                      a, b, c blocks              -> all_to_all(xb[poly] <- abc[poly]) x3
+ *         zk_shard_step(ZK_STEP_CROSS_INVERSE) top stages, in place in xb -> all_to_all(abc[poly] <- xb[poly]) x3
+ *         zk_shard_step(ZK_STEP_LOCAL)         local stages + coset shift -> all_to_all(xb <- abc) x3
+ *         zk_shard_step(ZK_STEP_CROSS_FORWARD) top stages, in place in xb -> all_to_all(abc <- xb) x3
+ *         zk_shard_step(ZK_STEP_FINISH)        h, MSM H, MSM C, joins     -> zk_prove_msm_collect + zk_prove_finish
+ *     `stream` (hipStream_t, may be NULL) is the stream the caller's collectives are ordered on: every call
+ *     first waits for what is enqueued on it and makes it wait for what the call enqueued. */
+enum { ZK_STEP_CROSS_INVERSE = 1, ZK_STEP_LOCAL = 2, ZK_STEP_CROSS_FORWARD = 3, ZK_STEP_FINISH = 4 };
+int zk_shard_info(zk_prover *p, uint64_t *block_elems, uint32_t *chain_partitioned);
+int zk_shard_set_exchange(zk_prover *p, void *d_abc, void *d_xb);
+int zk_shard_begin(zk_prover *p, const uint8_t *wtns, const void *d_wtns, const uint8_t *r32, const uint8_t *s32, void *stream);
+int zk_shard_step(zk_prover *p, int step, void *stream);
 
 /* Same as zk_prove_finish without a prover object: pure host code, usable on a rank that owns
  * no GPU (e.g. a coordinator).  vk points as in zk_zkey_view. */

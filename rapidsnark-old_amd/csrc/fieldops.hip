@@ -82,9 +82,13 @@ void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n
 
 // ---- CSR build on the device (the reference has no such step: it walks the records under 1024
 // striped locks on every proof, src/groth16.cpp:63-84).  Records are 44-byte packed, 4-byte aligned.
+// Rows outside [row_lo, row_hi) are skipped (a prover that holds one block of a partitioned chain keeps
+// only its rows); the range check covers every record either way.  Local row = c - row_lo, rows of
+// matrix B follow the nl = row_hi - row_lo rows of matrix A.
 __global__ __launch_bounds__(256) void k_csr_count(uint32_t *rowcount, uint32_t *err, const uint32_t *rec, uint64_t nCoefs, uint32_t n,
-                                                   uint32_t nVars) {
+                                                   uint32_t nVars, uint32_t row_lo, uint32_t row_hi) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t nl = row_hi - row_lo;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoefs; i += st) {
         const uint32_t *r = rec + i * 11;
         uint32_t m = r[0], c = r[1], sg = r[2];
@@ -92,18 +96,20 @@ __global__ __launch_bounds__(256) void k_csr_count(uint32_t *rowcount, uint32_t 
             atomicOr(err, 1u);
             continue;
         }
-        atomicAdd(&rowcount[(uint64_t)m * n + c], 1u);
+        if (c < row_lo || c >= row_hi) continue;
+        atomicAdd(&rowcount[(uint64_t)m * nl + (c - row_lo)], 1u);
     }
 }
 // The order of a row's terms depends on atomic arbitration; their (exact, modular) sum does not.
 __global__ __launch_bounds__(256) void k_csr_fill(uint32_t *col, Fr *val, uint32_t *cursor, const uint32_t *rec, uint64_t nCoefs, uint32_t n,
-                                                  uint32_t nVars) {
+                                                  uint32_t nVars, uint32_t row_lo, uint32_t row_hi) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t nl = row_hi - row_lo;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoefs; i += st) {
         const uint32_t *r = rec + i * 11;
         uint32_t m = r[0], c = r[1], sg = r[2];
-        if (m > 1u || c >= n || sg >= nVars) continue;
-        uint32_t pos = atomicAdd(&cursor[(uint64_t)m * n + c], 1u);
+        if (m > 1u || c >= n || sg >= nVars || c < row_lo || c >= row_hi) continue;
+        uint32_t pos = atomicAdd(&cursor[(uint64_t)m * nl + (c - row_lo)], 1u);
         col[pos] = sg;
         Fr v;
 #pragma unroll
@@ -113,15 +119,15 @@ __global__ __launch_bounds__(256) void k_csr_fill(uint32_t *col, Fr *val, uint32
 }
 
 void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor, uint32_t *err, const uint8_t *records,
-                      uint64_t nCoefs, uint32_t n, uint32_t nVars, hipStream_t s) {
-    const uint32_t rows = 2 * n;
+                      uint64_t nCoefs, uint32_t n, uint32_t nVars, uint32_t row_lo, uint32_t row_hi, hipStream_t s) {
+    const uint32_t rows = 2 * (row_hi - row_lo);
     ZK_HIP(hipMemsetAsync(cursor, 0, (size_t)rows * 4, s));
     ZK_HIP(hipMemsetAsync(err, 0, 4, s));
     const uint32_t g = grid_for(nCoefs ? nCoefs : 1, 256, 256 * 16);
-    hipLaunchKernelGGL(k_csr_count, dim3(g), dim3(256), 0, s, cursor, err, (const uint32_t *)records, nCoefs, n, nVars);
+    hipLaunchKernelGGL(k_csr_count, dim3(g), dim3(256), 0, s, cursor, err, (const uint32_t *)records, nCoefs, n, nVars, row_lo, row_hi);
     launch_exclusive_scan_u32(rowptr, cursor, rows, s);
     ZK_HIP(hipMemcpyAsync(cursor, rowptr, (size_t)rows * 4, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, col, val, cursor, (const uint32_t *)records, nCoefs, n, nVars);
+    hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, col, val, cursor, (const uint32_t *)records, nCoefs, n, nVars, row_lo, row_hi);
     ZK_LAUNCH_OK("csr build");
 }
 

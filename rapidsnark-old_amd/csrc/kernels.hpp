@@ -24,8 +24,10 @@ void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n
 // {u32 matrix, u32 row, u32 signal, 32-byte value}, src/groth16.hpp:27-35), built on the device.
 // rowptr: 2n + 1 words + msm_scan_extra_words(2n) of scan scratch; cursor: 2n words of scratch;
 // err: one word, set non-zero when a record is out of range (matrix > 1, row >= n, signal >= nVars).
+// Only the rows [row_lo, row_hi) of both matrices are kept (local row = row - row_lo; rowptr/cursor then
+// hold 2 * (row_hi - row_lo) rows); the range check covers every record.
 void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor, uint32_t *err, const uint8_t *records,
-                      uint64_t nCoefs, uint32_t n, uint32_t nVars, hipStream_t s);
+                      uint64_t nCoefs, uint32_t n, uint32_t nVars, uint32_t row_lo, uint32_t row_hi, hipStream_t s);
 // exclusive scan: out[i] = sum counts[0..i), out[total] = grand total; out holds total + 1 + msm_scan_extra_words(total) words
 void launch_exclusive_scan_u32(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s);
 
@@ -48,9 +50,21 @@ void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, ui
 // Batched in-place transforms of `batch` polynomials laid out at data + k*stride_elems.
 //  dif_inverse: natural -> bit-reversed, inverse twiddles, NO scaling
 //  dit_forward: bit-reversed -> natural, forward twiddles
-void launch_ntt_dif_inverse(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s);
+// local_logn < t.logn: only the stages over index bits [0, local_logn), on one contiguous block of
+// 2^local_logn elements of a transform partitioned across GPUs (twiddles of the full domain)
+#define NTT_FULL 0xffffffffu
+void launch_ntt_dif_inverse(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s, uint32_t local_logn = NTT_FULL);
 // premul (optional): table multiplied in as the first pass loads (the fused coset*1/n shift)
-void launch_ntt_dit_forward(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s, const Fr *premul = nullptr);
+void launch_ntt_dit_forward(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s, const Fr *premul = nullptr,
+                            uint32_t local_logn = NTT_FULL);
+// The stages over the TOP log_shards index bits of a transform partitioned across G = 2^log_shards GPUs
+// (see ntt.hip): xb = this GPU's exchange buffer [batch][G][n/G^2]; the result for block s is written to
+// out_base[s] + poly*out_poly_stride + out_offset + o'.  inverse: DIF stages + inverse twiddles.
+void launch_ntt_cross(bool inverse, const Fr *xb, Fr *const out_base[8], uint64_t out_poly_stride, uint64_t out_offset, uint32_t batch,
+                      const NttTables &t, uint32_t log_shards, uint32_t rank, hipStream_t s);
+// chunk s of every polynomial of this GPU's block (batch x n/G elements) -> slot `rank` of xb_of_gpu[s]
+void launch_chunk_scatter(Fr *const xb_of_gpu[8], const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, uint32_t rank,
+                          hipStream_t s);
 // Fr vectors: x*2^256 (zkey/ffiasm Montgomery form) -> x*2^(256+5*times) ; and 2^261 -> 2^256.
 // The NTT / SpMV kernels work on canonical words of the 2^261 form (field29.hpp).
 void launch_fr_to_internal(Fr *x, uint64_t n, int times, hipStream_t s);

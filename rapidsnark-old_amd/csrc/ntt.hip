@@ -166,11 +166,13 @@ static PassPlan plan_passes(uint32_t logn) {
     return p;   // ascending bit order: DIT runs 0..n-1, DIF runs n-1..0
 }
 
+// local_logn: size of the array the pass runs over (== logn unless this is one block of a transform
+// partitioned across GPUs: then the twiddles are still those of the full 2^logn domain)
 template <bool DIF>
 static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *tw, const Fr *premul, uint32_t logn,
-                     uint32_t lo, uint32_t t, uint32_t q, hipStream_t s) {
+                     uint32_t lo, uint32_t t, uint32_t q, hipStream_t s, uint32_t local_logn) {
     uint32_t T = t + q;
-    uint32_t tiles = 1u << (logn - T);
+    uint32_t tiles = 1u << (local_logn - T);
     size_t shmem = (size_t)36 << T;     // 9 limb planes; 72 KiB at T = 11 (opt-in above 64 KiB)
     static bool attr_set = false;
     if (!attr_set) {
@@ -182,20 +184,121 @@ static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *t
     ZK_LAUNCH_OK("ntt pass");
 }
 
-void launch_ntt_dif_inverse(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s) {
-    if (tb.logn == 0) return;
-    PassPlan p = plan_passes(tb.logn);
-    for (int i = p.n - 1; i >= 0; i--) run_pass<true>(data, stride, batch, tb.inv, nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
+// Stages over index bits [0, local_logn) of a 2^logn transform on a contiguous block of 2^local_logn
+// elements: the whole transform when local_logn == logn, one GPU's block of a partitioned one otherwise
+// (the stages over the top logn - local_logn bits are launch_ntt_cross's).
+void launch_ntt_dif_inverse(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s, uint32_t local_logn) {
+    if (local_logn == NTT_FULL) local_logn = tb.logn;
+    if (local_logn == 0) return;
+    PassPlan p = plan_passes(local_logn);
+    for (int i = p.n - 1; i >= 0; i--) run_pass<true>(data, stride, batch, tb.inv, nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s, local_logn);
 }
 
-void launch_ntt_dit_forward(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s, const Fr *premul) {
-    if (tb.logn == 0) {
+void launch_ntt_dit_forward(Fr *data, uint64_t stride, uint32_t batch, const NttTables &tb, hipStream_t s, const Fr *premul, uint32_t local_logn) {
+    if (local_logn == NTT_FULL) local_logn = tb.logn;
+    if (local_logn == 0) {
         if (premul) launch_fr_scale_by_table(data, stride, batch, premul, 1, s);
         return;
     }
-    PassPlan p = plan_passes(tb.logn);
+    PassPlan p = plan_passes(local_logn);
     for (int i = 0; i < p.n; i++)
-        run_pass<false>(data, stride, batch, tb.fwd, i == 0 ? premul : nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s);
+        run_pass<false>(data, stride, batch, tb.fwd, i == 0 ? premul : nullptr, tb.logn, p.lo[i], p.t[i], p.q[i], s, local_logn);
+}
+
+// ------------------------------------------------------------------ transform partitioned across G = 2^g GPUs
+// GPU r owns the contiguous block [r*n/G, (r+1)*n/G) of every polynomial (the same slices the H
+// point table is sharded by), so the stages over the low logn-g index bits are local (above) and
+// only the g stages over the TOP bits pair elements of different GPUs: element o of block s with
+// element o of block s ^ 2^k.  Those g stages are one radix-G butterfly per block offset o.  GPU r
+// does the butterflies of the offsets [r*n/G^2, (r+1)*n/G^2) for all G blocks: it receives that
+// chunk of every block (all-to-all #1: RCCL all_to_all_single between processes, peer writes inside
+// one process), runs k_ntt_cross on the G x n/G^2 exchange buffer `xb` (layout [poly][block][o']),
+// and the results travel back to their blocks (peer writes by the kernel itself, or all-to-all #2).
+// Traffic per GPU and transform: 2 x (G-1)/G of its block (28 MiB at 2^22, G = 8) — against the
+// 112 MiB an all-gather of the blocks would move.  DIF (inverse transform) runs the cross stages
+// FIRST, DIT (forward) runs them LAST; twiddles come from the full-size tables.
+struct CrossOut {
+    Fr *base[8];          // where the result for block s goes (peer memory or xb itself)
+};
+
+template <bool DIF, int LG>
+__global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, CrossOut out, uint64_t out_poly_stride, uint64_t out_offset,
+                                                   const TwEntry *tw, uint32_t logn, uint32_t rank, uint64_t chunk, uint64_t block) {
+    constexpr int G = 1 << LG;
+    const uint64_t op = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // offset inside this GPU's chunk
+    if (op >= chunk) return;
+    const uint32_t poly = blockIdx.y;
+    const Fr *src = xb + (uint64_t)poly * block + op;
+    const uint64_t o = (uint64_t)rank * chunk + op;                             // offset inside a block
+    Fr29 x[G];
+#pragma unroll
+    for (int sidx = 0; sidx < G; sidx++) x[sidx] = Fr29::load(load_el(src + (uint64_t)sidx * chunk));
+#pragma unroll
+    for (int t = 0; t < LG; t++) {
+        // DIF: bit b = logn-1-t, partner differs in block bit LG-1-t; DIT: b = logn-LG+t, block bit t
+        const int kb = DIF ? LG - 1 - t : t;
+        const uint32_t b = DIF ? logn - 1 - t : logn - LG + t;
+        const uint32_t tshift = logn - 1 - b;
+#pragma unroll
+        for (int sidx = 0; sidx < G; sidx++) {
+            if (sidx & (1 << kb)) continue;
+            const int s1 = sidx | (1 << kb);
+            // j = low b bits of the global index s*block + o
+            const uint64_t j = (uint64_t)(sidx & ((1 << kb) - 1)) * block + o;
+            const Fr29 w = load_tw(tw + (j << tshift));
+            Fr29 u = x[sidx], v = x[s1];
+            if (DIF) {
+                x[sidx] = Fr29::add(u, v);
+                x[s1] = Fr29::mul(Fr29::sub(u, v), w);
+            } else {
+                v = Fr29::mul(v, w);
+                x[sidx] = Fr29::add(u, v);
+                x[s1] = Fr29::sub(u, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < G; sidx++)
+        store_el(out.base[sidx] + (uint64_t)poly * out_poly_stride + out_offset + op, Fr29::store(x[sidx]));
+}
+
+void launch_ntt_cross(bool inverse, const Fr *xb, Fr *const out_base[8], uint64_t out_poly_stride, uint64_t out_offset, uint32_t batch,
+                      const NttTables &tb, uint32_t log_shards, uint32_t rank, hipStream_t s) {
+    if (log_shards == 0) return;
+    const uint64_t block = 1ull << (tb.logn - log_shards), chunk = block >> log_shards;
+    CrossOut out;
+    for (int i = 0; i < 8; i++) out.base[i] = i < (1 << log_shards) ? out_base[i] : nullptr;
+    const dim3 grid((uint32_t)((chunk + 255) / 256), batch), blk(256);
+    const TwEntry *tw = inverse ? tb.inv : tb.fwd;
+#define ZK_CROSS(D, L) hipLaunchKernelGGL((k_ntt_cross<D, L>), grid, blk, 0, s, xb, out, out_poly_stride, out_offset, tw, tb.logn, rank, chunk, block)
+    if (inverse) {
+        if (log_shards == 1) ZK_CROSS(true, 1); else if (log_shards == 2) ZK_CROSS(true, 2); else ZK_CROSS(true, 3);
+    } else {
+        if (log_shards == 1) ZK_CROSS(false, 1); else if (log_shards == 2) ZK_CROSS(false, 2); else ZK_CROSS(false, 3);
+    }
+#undef ZK_CROSS
+    ZK_LAUNCH_OK("ntt cross-GPU stages");
+}
+
+// all-to-all #1 inside one process: chunk s of every polynomial of this GPU's block -> slot `rank` of
+// GPU s's exchange buffer (peer writes over xGMI; coalesced 32-byte elements)
+struct ChunkDst {
+    Fr *base[8];
+};
+__global__ __launch_bounds__(256) void k_chunk_scatter(ChunkDst dst, const Fr *blockdata, uint64_t chunk, uint64_t block, uint32_t rank) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element inside this GPU's block
+    if (i >= block) return;
+    const uint32_t poly = blockIdx.y;
+    const uint64_t sidx = i / chunk, op = i - sidx * chunk;
+    store_el(dst.base[sidx] + (uint64_t)poly * block + (uint64_t)rank * chunk + op, load_el(blockdata + (uint64_t)poly * block + i));
+}
+void launch_chunk_scatter(Fr *const xb_of_gpu[8], const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, uint32_t rank,
+                          hipStream_t s) {
+    const uint64_t block = 1ull << (logn - log_shards), chunk = block >> log_shards;
+    ChunkDst d;
+    for (int i = 0; i < 8; i++) d.base[i] = i < (1 << log_shards) ? xb_of_gpu[i] : nullptr;
+    hipLaunchKernelGGL(k_chunk_scatter, dim3((uint32_t)((block + 255) / 256), batch), dim3(256), 0, s, d, blockdata, chunk, block, rank);
+    ZK_LAUNCH_OK("chunk scatter");
 }
 
 // ------------------------------------------------------------------ pointwise helpers

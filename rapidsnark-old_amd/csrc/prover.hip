@@ -26,6 +26,16 @@
 
 using namespace zk;
 
+// A prover uses six HIP streams (two compute chains, two high-priority follow-up streams, the
+// upload stream, the finishing stream) next to the application's own.  The HIP runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with streams aliased onto one queue the
+// witness upload of proof k+1 queued behind work of proof k and the proofs stopped overlapping —
+// measured at 2^22 with host witnesses: 44.2 ms per proof with 4 queues, 36.9 with 8 (resident
+// witnesses: 35.7).  The variable is read when the HIP runtime initialises, so this only helps when
+// the library is loaded before the process's first HIP call; hosts should export it themselves
+// (INTEGRATION.md).  An explicit setting by the user is never overridden.
+__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace {
 
 #define HIP_TRY(expr) ZK_HIP(expr)
@@ -99,6 +109,13 @@ struct SortBufs {
 
 }   // namespace
 
+// pageable witness -> pinned staging, run as a host function on the upload stream
+struct StageJob {
+    uint8_t *dst;
+    const uint8_t *src;
+    size_t bytes;
+};
+
 struct zk_prover {
     int device = 0;
     uint32_t flags = 0;
@@ -147,6 +164,7 @@ struct zk_prover {
         // k+1's upload runs (on its own stream) while proof k is still computing.
         DevBuf<Fr> wtns_dev;
         uint8_t *wtns_pin = nullptr;
+        StageJob stage{nullptr, nullptr, 0};
         hipEvent_t ev_h2d = nullptr, ev_h2d_start = nullptr;
         uint8_t r32[32], s32[32];
         bool have_r = false, have_s = false;
@@ -162,9 +180,22 @@ struct zk_prover {
             if (ev_h2d_start) (void)hipEventDestroy(ev_h2d_start);
         }
     };
-    ProofSlot slot[2];
+    ProofSlot slot[ZK_MAX_IN_FLIGHT];
     uint32_t next_submit = 0, next_collect = 0, in_flight = 0;
     uint32_t wbits = 0;
+    // ---- chain partitioned across the shards (ZK_FLAG_PARTITIONED_CHAIN; shard_count = 2^log_shards):
+    // this prover computes rows [sh.lo, sh.hi) of a, b, c only, runs the local stages of the six
+    // transforms on that block and meets the other shards in the cross stages (ntt.hip)
+    bool part = false;
+    uint32_t log_shards = 0;
+    uint64_t nloc = 0;                                   // rows of a, b, c, h held here (= domainSize unless part)
+    DevBuf<Fr> xb;                                       // exchange buffer of the cross stages: [3][shard][nloc / shards]
+    Fr *abc_use = nullptr, *xb_use = nullptr;            // own buffers, or the caller's (zk_shard_set_exchange)
+    Fr *peer_abc[8] = {nullptr}, *peer_xb[8] = {nullptr};   // inside one process: every shard's buffers (zk_multi_prover)
+    bool have_peers = false;
+    int phase_open = -1, phase_next = 0;                 // slot being submitted phase by phase (-1: none), next phase
+    hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;
+    uint32_t log_shards_chain() const { return part ? log_shards : 0; }
     hipStream_t stream3 = nullptr, stream4 = nullptr;   // follow-up streams of stream2 / stream: partial merges + bucket reductions
     hipStream_t stream_fin = nullptr;                   // joins a proof's streams and copies its window sums to the host
     hipStream_t stream_h2d = nullptr;                   // witness uploads of host-witness proofs
@@ -176,6 +207,8 @@ struct zk_prover {
         // proofs may still be in flight (submitted, never collected): drain before anything is released
         for (hipStream_t st : {stream_h2d, stream, stream2, stream3, stream4, stream_fin})
             if (st) (void)hipStreamSynchronize(st);
+        if (ev_ext_in) (void)hipEventDestroy(ev_ext_in);
+        if (ev_ext_out) (void)hipEventDestroy(ev_ext_out);
         if (stream_h2d) (void)hipStreamDestroy(stream_h2d);
         if (stream_fin) (void)hipStreamDestroy(stream_fin);
         if (stream3) (void)hipStreamDestroy(stream3);
@@ -356,11 +389,27 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     hipStream_t s = p->stream;
     clk.lap("device + streams", s);
 
+    // --- this shard's contiguous slices of the witness indices and of the domain
+    p->sv = shard_slice(nV, p->shard_index, p->shard_count);
+    p->sh = shard_slice(n, p->shard_index, p->shard_count);
+    p->part = (p->flags & ZK_FLAG_PARTITIONED_CHAIN) != 0 && p->shard_count > 1;
+    if (p->part) {
+        uint32_t lg = 0;
+        while ((1u << lg) < p->shard_count) lg++;
+        if ((1u << lg) != p->shard_count || lg > 3) throw std::invalid_argument("partitioned chain: shard_count must be 2, 4 or 8");
+        if (p->logn < 2 * lg) throw std::invalid_argument("partitioned chain: domainSize must be at least shard_count^2");
+        p->log_shards = lg;
+    }
+    p->nloc = p->part ? p->sh.size() : n;
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_out, hipEventDisableTiming));
+
     // --- CSR (src/groth16.cpp:38: records start 4 bytes into section 4), built on the device from
-    // the raw records (the host pass over 4n random rows was the largest single part of create)
+    // the raw records (the host pass over 4n random rows was the largest single part of create);
+    // a partitioned prover keeps the rows of its own block only
     {
         const uint64_t nnz = z->nCoefs;
-        const uint32_t rows = 2 * z->domainSize;
+        const uint32_t rows = 2 * (uint32_t)p->nloc;
         DevBuf<uint8_t> raw;
         DevBuf<uint32_t> cursor, err;
         raw.alloc(nnz ? nnz * 44 : 4);
@@ -371,8 +420,9 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->csr_val.alloc(nnz ? nnz : 1);
         if (nnz) HIP_TRY(hipMemcpyAsync(raw.p, (const uint8_t *)z->coefs + 4, nnz * 44, hipMemcpyHostToDevice, s));
         clk.lap("coefficient records upload", s);
-        launch_csr_build(p->csr_rowptr.p, p->csr_col.p, p->csr_val.p, cursor.p, err.p, raw.p, nnz, z->domainSize, z->nVars, s);
-        launch_fr_to_internal(p->csr_val.p, nnz, 2, s);      // value*2^512 -> value*2^522 (see k_spmv_abc)
+        launch_csr_build(p->csr_rowptr.p, p->csr_col.p, p->csr_val.p, cursor.p, err.p, raw.p, nnz, z->domainSize, z->nVars,
+                         p->part ? (uint32_t)p->sh.lo : 0u, p->part ? (uint32_t)p->sh.hi : z->domainSize, s);
+        launch_fr_to_internal(p->csr_val.p, nnz, 2, s);      // value*2^512 -> value*2^522 (see k_spmv_abc); unused tail entries are zero
         uint32_t bad = 0;
         HIP_TRY(hipMemcpyAsync(&bad, err.p, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -388,9 +438,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     launch_ntt_build_tables(p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p, p->logn, s);
     clk.lap("twiddle tables", s);
 
-    // --- point tables: this shard's contiguous slices (SURVEY §8e)
-    p->sv = shard_slice(nV, p->shard_index, p->shard_count);
-    p->sh = shard_slice(n, p->shard_index, p->shard_count);
+    // --- point tables: this shard's contiguous slices
     const uint64_t nv = p->sv.size(), nh = p->sh.size();
     p->precomp = (p->flags & ZK_FLAG_PRECOMP) != 0;
     p->sort_h.alloc(nh, wbits, p->precomp);
@@ -451,20 +499,35 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     }
 
     // --- workspace (slot 0 was allocated above; slot 1 appears with the first overlapped submit)
-    p->abc.alloc(3 * n);
-    p->h.alloc(n);
+    p->abc.alloc(3 * p->nloc);
+    p->h.alloc(p->nloc);
+    if (p->part) p->xb.alloc(3 * p->nloc);
+    p->abc_use = p->abc.p;
+    p->xb_use = p->xb.p;
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
     clk.lap(p->precomp ? "window pre-computation" : "finish", s);
     *out = p.release();
 }
 
 // Witness of a host-witness proof -> the slot's HBM copy, on the upload stream.  A caller buffer in
-// pinned memory (zk_host_alloc, or registered by the caller) is copied from directly; a pageable
-// one (the reference's contract: Prover::prove(FrElement *wtns), src/groth16.hpp:101) goes through
-// the slot's pinned staging buffer first (threaded memcpy), so that the H2D itself is always a
-// true asynchronous DMA that proof k's kernels hide.  Returns after the caller's buffer has been
-// read only in the pageable case; a pinned buffer must stay untouched until the proof is collected.
-static const Fr *upload_witness(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *h_wtns) {
+// pinned memory (zk_host_alloc, or registered by the caller) is read by the DMA engine directly; a
+// pageable one (the reference's contract: Prover::prove(FrElement *wtns), src/groth16.hpp:101) is
+// first copied to the slot's pinned staging buffer BY A HOST FUNCTION ON THE UPLOAD STREAM, so the
+// calling thread returns at once and goes on enqueueing the proof (measured at 2^22: staging inside
+// the call cost 5 ms per proof — the two-in-flight overlap has to wait for the next submit).  Either
+// way the caller's buffer must stay valid and untouched until the proof has been collected.
+static void stage_job_run(void *arg) {
+    const StageJob *j = (const StageJob *)arg;
+    const size_t nt = j->bytes >= ((size_t)8 << 20) ? 4 : 1, per = (j->bytes / nt + 63) & ~(size_t)63;
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; t++) {
+        const size_t lo = t * per, hi = lo + per < j->bytes ? lo + per : j->bytes;
+        if (lo < hi) th.emplace_back([=] { memcpy(j->dst + lo, j->src + lo, hi - lo); });
+    }
+    memcpy(j->dst, j->src, per < j->bytes ? per : j->bytes);
+    for (auto &t : th) t.join();
+}
+static const Fr *upload_witness(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *h_wtns, hipEvent_t src_ready = nullptr) {
     const size_t bytes = (size_t)p->nVars * 32;
     if (!q.wtns_dev.p) q.wtns_dev.alloc(p->nVars);
     if (!q.ev_h2d) {
@@ -475,57 +538,79 @@ static const Fr *upload_witness(zk_prover *p, zk_prover::ProofSlot &q, const uin
     bool pinned = hipPointerGetAttributes(&attr, h_wtns) == hipSuccess && attr.type == hipMemoryTypeHost;
     (void)hipGetLastError();                       // an unregistered pointer is reported as an error: not one
     const uint8_t *src = h_wtns;
+    hipStream_t sh = p->stream_h2d;
+    if (src_ready) HIP_TRY(hipStreamWaitEvent(sh, src_ready, 0));      // the (pinned) source is still being filled
     if (!pinned) {
         if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes, hipHostMallocDefault));
-        const size_t nt = bytes >= ((size_t)8 << 20) ? 4 : 1, per = (bytes / nt + 63) & ~(size_t)63;
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; t++) {
-            const size_t lo = t * per, hi = lo + per < bytes ? lo + per : bytes;
-            if (lo < hi) th.emplace_back([=, &q] { memcpy(q.wtns_pin + lo, h_wtns + lo, hi - lo); });
-        }
-        memcpy(q.wtns_pin, h_wtns, per < bytes ? per : bytes);
-        for (auto &t : th) t.join();
+        q.stage = StageJob{q.wtns_pin, h_wtns, bytes};
+        static const bool sync_stage = getenv("ZKHIP_STAGE_SYNC") != nullptr;      // tuning aid: stage inside the call
+        if (sync_stage) stage_job_run(&q.stage);
+        else HIP_TRY(hipLaunchHostFunc(sh, stage_job_run, &q.stage));
         src = q.wtns_pin;
     }
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
-    if (tm) HIP_TRY(hipEventRecord(q.ev_h2d_start, p->stream_h2d));
-    HIP_TRY(hipMemcpyAsync(q.wtns_dev.p, src, bytes, hipMemcpyHostToDevice, p->stream_h2d));
-    HIP_TRY(hipEventRecord(q.ev_h2d, p->stream_h2d));
-    if (tm) HIP_TRY(hipEventRecord(q.ev[12], p->stream_h2d));
+    if (tm) HIP_TRY(hipEventRecord(q.ev_h2d_start, sh));
+    HIP_TRY(hipMemcpyAsync(q.wtns_dev.p, src, bytes, hipMemcpyHostToDevice, sh));
+    HIP_TRY(hipEventRecord(q.ev_h2d, sh));
+    if (tm) HIP_TRY(hipEventRecord(q.ev[12], sh));
     return q.wtns_dev.p;
 }
 
 // Steps 1-10 of prove() (src/groth16.cpp:52-204), device part: everything is enqueued, nothing waits.
-// Exactly one of d_wtns (device pointer, nVars x 32 B, must stay valid until the proof is collected)
-// and h_wtns (host pointer) is given.  Caller holds p->mtx.
-static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
-    if (p->in_flight >= 2) throw std::invalid_argument("two proofs already in flight: collect one first");
+// The work of one proof is split into phases so that a prover holding one block of a chain that is
+// PARTITIONED across GPUs (ZK_FLAG_PARTITIONED_CHAIN) can stop where the blocks have to be exchanged:
+//   front      : slot, witness upload, sort(w) + MSM B2/A/B1 on stream 2, a = A.w, b = B.w, c = a o b
+//   [cross DIF]: the log2(G) top stages of the three inverse transforms          (partitioned only)
+//   local      : the local stages of the inverse and forward transforms, coset shift fused
+//   [cross DIT]: the log2(G) top stages of the three forward transforms          (partitioned only)
+//   back       : h, sort(h), MSM H and C, joins, D2H of the window sums
+// An unpartitioned prover runs front + local + back back to back (submit_locked).  Exactly one of
+// d_wtns (device pointer, nVars x 32 B, must stay valid until the proof is collected) and h_wtns
+// (host pointer) is given.  Caller holds p->mtx.
+namespace {
+
+struct PhaseCtx {
+    zk_prover *p;
+    zk_prover::ProofSlot &q;
+    hipStream_t s, s2, s3, s4;
+    bool tm;
+    uint32_t tbw, tbh, Ww;
+    uint64_t ew, eh;
+    MsmPlan pw;
+    G1XYZZ *bA, *bB1, *bC, *bH;
+    PhaseCtx(zk_prover *p_, int si) : p(p_), q(p_->slot[si]) {
+        s = p->stream; s2 = p->stream2; s3 = p->stream3; s4 = p->stream4;
+        tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
+        tbw = q.sort_w.total_buckets(); tbh = p->sort_h.total_buckets();
+        ew = q.sort_w.max_entries(); eh = p->sort_h.max_entries();
+        pw = q.sort_w.plan; Ww = pw.sets;
+        bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
+    }
+    void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
+    AccumTail tail_of(int m) const { AccumTail t; t.stream = (m == 2 || m == 3) ? s4 : s3; t.l1_done = q.ev_l1[m]; return t; }
+    hipStream_t after(hipStream_t own) const { return s4 ? s4 : own; }
+    NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
+};
+
+int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32, hipEvent_t src_ready = nullptr) {
     DeviceGuard g(p->device);
-    const int si = (int)(p->next_submit & 1u);
+    if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("three proofs already in flight: collect one first");
+    if (p->phase_open >= 0) throw std::invalid_argument("a proof is still being submitted phase by phase");
+    const int si = (int)(p->next_submit % ZK_MAX_IN_FLIGHT);
     alloc_slot(p, si);
-    zk_prover::ProofSlot &q = p->slot[si];
+    PhaseCtx c(p, si);
+    zk_prover::ProofSlot &q = c.q;
     const bool staged = h_wtns != nullptr;
-    if (staged) d_wtns = upload_witness(p, q, h_wtns);
+    if (staged) d_wtns = upload_witness(p, q, h_wtns, src_ready);
     q.host_witness = staged;
     q.have_r = r32 != nullptr;
     q.have_s = s32 != nullptr;
     if (r32) memcpy(q.r32, r32, 32);
     if (s32) memcpy(q.s32, s32, 32);
+    hipStream_t s = c.s, s2 = c.s2, s3 = c.s3;
+    const bool tm = c.tm;
 
-    hipStream_t s = p->stream;
-    const uint64_t n = p->domainSize;
-    const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
-    auto mark = [&](int i) {
-        if (tm) HIP_TRY(hipEventRecord(q.ev[i], s));
-    };
-    Fr *a = p->abc.p, *b = p->abc.p + n, *c = p->abc.p + 2 * n;
-
-    const uint32_t tbw = q.sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
-    G1XYZZ *bA = q.buckets_g1.p, *bB1 = bA + tbw, *bC = bB1 + tbw, *bH = bC + tbw;
-    const uint64_t ew = q.sort_w.max_entries(), eh = p->sort_h.max_entries();
-    hipStream_t s2 = p->stream2;
-
-    mark(0);
+    c.mark(0);
     // ---- stream2: work that depends on the witness only (the reference runs it AFTER the FFT
     // chain, src/groth16.cpp:180-204; it is independent of it): sort(w) once, then MSM B2, A, B1
     // over the shared bucket order.  MSM C joins stream 1 behind MSM H to balance the streams.
@@ -541,50 +626,99 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns,
     // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: on their
     // own streams they neither delay the next level-1 kernel of their MSM's stream nor pile up
     // behind the last one
-    hipStream_t s3 = p->stream3, s4 = p->stream4;
-    auto tail_of = [&](int m) { AccumTail t; t.stream = (m == 2 || m == 3) ? s4 : s3; t.l1_done = q.ev_l1[m]; return t; };
-    auto after = [&](hipStream_t own) { return s4 ? s4 : own; };
-    const uint32_t Ww = q.sort_w.plan.sets;     // window sums per MSM
-    const MsmPlan pw = q.sort_w.plan;
-    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4].p, q.acc_flag[4].p, s2, tm ? &q.ev[10] : nullptr, tail_of(4));
+    const uint32_t tbw = c.tbw, Ww = c.Ww;
+    const uint64_t ew = c.ew;
+    const MsmPlan pw = c.pw;
+    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4].p, q.acc_flag[4].p, s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
     if (s3) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s3);
-    launch_msm_accum_g1(bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0].p, q.acc_key[0].p, q.acc_flag[0].p, s2, tm ? &q.ev[8] : nullptr, tail_of(0));
-    if (s3) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, bA, 1, pw, s3);
-    launch_msm_accum_g1(bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1].p, q.acc_key[1].p, q.acc_flag[1].p, s2, nullptr, tail_of(1));
+    launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0].p, q.acc_key[0].p, q.acc_flag[0].p, s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
+    if (s3) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, s3);
+    launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1].p, q.acc_key[1].p, q.acc_flag[1].p, s2, nullptr, c.tail_of(1));
     if (s3) {
-        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), bB1, 1, pw, s3);
+        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, s3);
     } else {
         // bucket reductions stay on the stream of their MSMs
         launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
-        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, bA, 2, pw, s2);
+        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 2, pw, s2);
     }
     HIP_TRY(hipEventRecord(q.ev_join, s2));
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
-    // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96)
+    // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96) — on the rows this prover holds
+    const uint64_t nl = p->nloc;
+    Fr *abc = p->abc_use;
     CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
-    launch_spmv_abc(a, b, c, csr, d_wtns, p->domainSize, s);
-    mark(1);
-    // 4: three coset evaluations (src/groth16.cpp:98-155), batched, no bit-reversal pass
-    NttTables tb{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p};
-    launch_ntt_dif_inverse(p->abc.p, n, 3, tb, s);
-    launch_ntt_dit_forward(p->abc.p, n, 3, tb, s, p->tw_coset.p);     // coset shift * 1/n fused into the first pass
+    launch_spmv_abc(abc, abc + nl, abc + 2 * nl, csr, d_wtns, (uint32_t)nl, s);
+    c.mark(1);
+    p->phase_open = si;
+    p->phase_next = p->part ? 1 : 2;
+    return si;
+}
+
+// The log2(G) stages over the top index bits of the three transforms (ntt.hip, launch_ntt_cross).
+// Inside one process (peer buffers known) this prover first pushes chunk s of its block into GPU s's
+// exchange buffer and records `pushed`; the caller makes every prover wait for every other's event
+// (cross_wait) before cross_run.  Between processes the caller has done the all-to-all itself.
+void phase_cross_push(zk_prover *p, hipEvent_t pushed) {
+    DeviceGuard g(p->device);
+    launch_chunk_scatter(p->peer_xb, p->abc_use, 3, p->logn, p->log_shards, p->shard_index, p->stream);
+    HIP_TRY(hipEventRecord(pushed, p->stream));
+}
+void phase_cross_run(zk_prover *p, bool inverse, hipEvent_t done) {
+    if (p->phase_open < 0 || p->phase_next != (inverse ? 1 : 3)) throw std::invalid_argument("chain phases out of order");
+    DeviceGuard g(p->device);
+    PhaseCtx c(p, p->phase_open);
+    const uint64_t nl = p->nloc, chunk = nl >> p->log_shards;
+    if (p->have_peers) {
+        // results go straight into the owners' blocks (peer writes)
+        launch_ntt_cross(inverse, p->xb_use, p->peer_abc, nl, (uint64_t)p->shard_index * chunk, 3, c.tables(), p->log_shards, p->shard_index, c.s);
+    } else {
+        Fr *inplace[8];
+        for (uint32_t i = 0; i < 8; i++) inplace[i] = p->xb_use + (uint64_t)i * chunk;
+        launch_ntt_cross(inverse, p->xb_use, inplace, nl, 0, 3, c.tables(), p->log_shards, p->shard_index, c.s);
+    }
+    if (done) HIP_TRY(hipEventRecord(done, c.s));
+    p->phase_next = inverse ? 2 : 4;
+}
+
+void phase_local(zk_prover *p) {
+    if (p->phase_open < 0 || p->phase_next != 2) throw std::invalid_argument("chain phases out of order");
+    DeviceGuard g(p->device);
+    PhaseCtx c(p, p->phase_open);
+    // 4: three coset evaluations (src/groth16.cpp:98-155), batched, no bit-reversal pass; on a partitioned
+    // chain only the stages over the low logn - log2(G) index bits of this prover's block
+    const uint32_t local_logn = p->logn - p->log_shards_chain();
+    const uint64_t nl = p->nloc;
+    NttTables tb = c.tables();
+    launch_ntt_dif_inverse(p->abc_use, nl, 3, tb, c.s, local_logn);
+    launch_ntt_dit_forward(p->abc_use, nl, 3, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
+    p->phase_next = p->part ? 3 : 4;
+}
+
+void phase_back(zk_prover *p) {
+    if (p->phase_open < 0 || p->phase_next != 4) throw std::invalid_argument("chain phases out of order");
+    DeviceGuard g(p->device);
+    PhaseCtx c(p, p->phase_open);
+    zk_prover::ProofSlot &q = c.q;
+    hipStream_t s = c.s, s3 = c.s3, s4 = c.s4;
+    const uint64_t nl = p->nloc;
+    Fr *abc = p->abc_use;
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
-    launch_abc_to_h(p->h.p, a, b, c, n, s);
-    mark(2);
-    p->sort_h.run(p->h.p + p->sh.lo, s);
-    mark(3);
+    launch_abc_to_h(p->h.p, abc, abc + nl, abc + 2 * nl, nl, s);
+    c.mark(2);
+    p->sort_h.run(p->h.p + (p->part ? 0 : p->sh.lo), s);
+    c.mark(3);
     // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
-    launch_msm_accum_g1(bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, tbh, eh, q.acc_ws_g1[3].p, q.acc_key[3].p, q.acc_flag[3].p, s, nullptr, tail_of(3));
-    mark(4);
-    launch_msm_reduce_g1(q.wsum_g1.p + 3 * Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, pw), bH, 1, p->sort_h.plan, after(s));
+    launch_msm_accum_g1(c.bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, c.tbh, c.eh, q.acc_ws_g1[3].p, q.acc_key[3].p, q.acc_flag[3].p, s, nullptr, c.tail_of(3));
+    c.mark(4);
+    launch_msm_reduce_g1(q.wsum_g1.p + 3 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, c.pw), c.bH, 1, p->sort_h.plan, c.after(s));
     // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w).  (Moving it to
     // stream2 was measured slower at every shard count; so was raising stream 1's priority for
     // anything but the two-in-flight throughput of 4-8 shards.)
     HIP_TRY(hipStreamWaitEvent(s, q.ev_sortw, 0));
-    launch_msm_accum_g1(bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, tbw, ew, q.acc_ws_g1[2].p, q.acc_key[2].p, q.acc_flag[2].p, s, nullptr, tail_of(2));
-    launch_msm_reduce_g1(q.wsum_g1.p + 2 * Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, pw), bC, 1, pw, after(s));
-    mark(5);
+    launch_msm_accum_g1(c.bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, c.tbw, c.ew, q.acc_ws_g1[2].p, q.acc_key[2].p, q.acc_flag[2].p, s, nullptr, c.tail_of(2));
+    launch_msm_reduce_g1(q.wsum_g1.p + 2 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, c.pw), c.bC, 1, c.pw, c.after(s));
+    c.mark(5);
     HIP_TRY(hipEventRecord(q.ev_main, s));
 
     // ---- join on the finishing stream (the main streams go straight on to the next proof):
@@ -598,14 +732,34 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns,
         HIP_TRY(hipEventRecord(q.ev_f4, s4));
         HIP_TRY(hipStreamWaitEvent(sf, q.ev_f4, 0));
     }
-    if (tm) HIP_TRY(hipEventRecord(q.ev[6], sf));
+    if (c.tm) HIP_TRY(hipEventRecord(q.ev[6], sf));
     HIP_TRY(hipMemcpyAsync(q.w1, q.wsum_g1.p, q.w1_bytes, hipMemcpyDeviceToHost, sf));
     HIP_TRY(hipMemcpyAsync(q.w2, q.wsum_g2.p, q.w2_bytes, hipMemcpyDeviceToHost, sf));
     HIP_TRY(hipEventRecord(q.ev_done, sf));
     HIP_TRY(hipGetLastError());          // nothing of the ~100 launches above may have been refused
     q.busy = true;
+    p->phase_open = -1;
     p->next_submit++;
     p->in_flight++;
+}
+
+// a failed phase must not leave the prover wedged in "being submitted"
+struct PhaseAbort {
+    zk_prover *p;
+    bool armed = true;
+    ~PhaseAbort() { if (armed) p->phase_open = -1; }
+};
+
+}   // namespace
+
+static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
+    if (p->part) throw std::invalid_argument("this prover holds one block of a partitioned chain: drive it through zk_multi_prove* or zk_shard_*");
+    DeviceGuard g(p->device);
+    PhaseAbort guard{p};
+    phase_front(p, d_wtns, h_wtns, r32, s32);
+    phase_local(p);
+    phase_back(p);
+    guard.armed = false;
 }
 
 // Waits for the oldest proof in flight, then the host part: Horner over the window sums
@@ -613,7 +767,7 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns,
 static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out) {
     if (!p->in_flight) throw std::invalid_argument("no proof in flight");
     DeviceGuard g(p->device);
-    zk_prover::ProofSlot &q = p->slot[p->next_collect & 1u];
+    zk_prover::ProofSlot &q = p->slot[p->next_collect % ZK_MAX_IN_FLIGHT];
     const hipError_t done = hipEventSynchronize(q.ev_done);
     // the slot is retired whatever happened (a failed proof must not wedge the queue), but only
     // AFTER the wait: nobody may reuse its buffers while its kernels can still run
@@ -801,6 +955,284 @@ int zk_prover_timings(zk_prover *p, double *ms, uint32_t n) {
         if (!p || !ms) throw std::invalid_argument("null argument");
         if (!(p->flags & ZK_FLAG_TIMINGS)) throw std::invalid_argument("prover created without ZK_FLAG_TIMINGS");
         for (uint32_t i = 0; i < n && i < ZK_T_COUNT; i++) ms[i] = p->timings[i];
+    });
+}
+
+}   // extern "C"
+
+// ------------------------------------------------------------------ one proof on several GPUs
+// (a) zk_shard_*: one process per GPU (torch.distributed / RCCL): the caller owns the exchange of the
+//     chain's blocks — four all_to_all per proof on buffers it registered — and drives the phases.
+// (b) zk_multi_prover: all GPUs of the node in ONE process (what the reference's CLI and server are):
+//     one shard prover per device, phases enqueued device by device, blocks exchanged by peer writes
+//     over xGMI, cross-device ordering by events (hipStreamWaitEvent across devices).
+namespace {
+
+// stream 1 of the prover <-> the caller's stream (on which its collectives are ordered)
+void ext_in(zk_prover *p, void *stream) {
+    if (!stream) return;
+    HIP_TRY(hipEventRecord(p->ev_ext_in, (hipStream_t)stream));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_ext_in, 0));
+}
+void ext_out(zk_prover *p, void *stream) {
+    if (!stream) return;
+    HIP_TRY(hipEventRecord(p->ev_ext_out, p->stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->ev_ext_out, 0));
+}
+
+}   // namespace
+
+struct zk_multi_prover {
+    std::vector<zk_prover *> shard;
+    std::vector<hipEvent_t> ev[4];       // per shard: chunks pushed (DIF), cross DIF done, chunks pushed (DIT), cross DIT done
+    uint8_t *stage_pin[ZK_MAX_IN_FLIGHT] = {nullptr};
+    hipEvent_t ev_staged[ZK_MAX_IN_FLIGHT] = {nullptr};
+    StageJob stage[ZK_MAX_IN_FLIGHT];
+    uint64_t submitted = 0;
+    bool part = false;
+    std::mutex mtx;
+    ~zk_multi_prover() {
+        for (zk_prover *q : shard) zk_prover_destroy(q);        // drains every stream first
+        for (auto &v : ev) for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e);
+        for (auto &b : stage_pin) if (b) (void)hipHostFree(b);
+        for (auto &e : ev_staged) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+void multi_create(zk_multi_prover **out, const zk_zkey_view *z, const int32_t *devices, uint32_t nd, const zk_opts *o) {
+    if (!out || !z || !devices || nd == 0) throw std::invalid_argument("null argument");
+    if (nd > 8) throw std::invalid_argument("at most 8 devices");
+    need_device_count();
+    std::unique_ptr<zk_multi_prover> mp(new zk_multi_prover());
+    uint32_t lg = 0;
+    while ((1u << lg) < nd) lg++;
+    uint32_t logn = 0;
+    while ((1ull << logn) < z->domainSize) logn++;
+    const bool can_part = nd > 1 && (1u << lg) == nd && logn >= 2 * lg && !getenv("ZKHIP_REPLICATED_CHAIN");
+    mp->part = can_part;
+    for (uint32_t g = 0; g < nd; g++) {
+        zk_opts so;
+        memset(&so, 0, sizeof so);
+        so.device = devices[g];
+        so.shard_index = g;
+        so.shard_count = nd;
+        so.window_bits = o ? o->window_bits : 0;
+        so.flags = (o ? o->flags : 0) & ~ZK_FLAG_PARTITIONED_CHAIN;
+        if (can_part) so.flags |= ZK_FLAG_PARTITIONED_CHAIN;
+        zk_prover *q = nullptr;
+        prover_create(&q, z, &so);
+        mp->shard.push_back(q);
+    }
+    // peer access between every pair of distinct devices (xGMI inside a node)
+    for (uint32_t a = 0; a < nd; a++)
+        for (uint32_t b = 0; b < nd; b++) {
+            if (devices[a] == devices[b]) continue;
+            DeviceGuard g(devices[a]);
+            hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else HIP_TRY(e);
+        }
+    for (uint32_t a = 0; a < nd; a++) {
+        zk_prover *q = mp->shard[a];
+        for (uint32_t b = 0; b < nd; b++) {
+            q->peer_abc[b] = mp->shard[b]->abc_use;
+            q->peer_xb[b] = mp->shard[b]->xb_use;
+        }
+        q->have_peers = can_part;
+        DeviceGuard g(q->device);
+        for (auto &v : mp->ev) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            v.push_back(e);
+        }
+    }
+    {
+        DeviceGuard g(mp->shard[0]->device);
+        for (auto &e : mp->ev_staged) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    *out = mp.release();
+}
+
+// every stream-1 waits for the given event of EVERY shard (the all-to-all dependency of a cross step)
+void wait_all(zk_multi_prover *mp, int which) {
+    for (zk_prover *q : mp->shard) {
+        DeviceGuard g(q->device);
+        for (size_t b = 0; b < mp->shard.size(); b++) HIP_TRY(hipStreamWaitEvent(q->stream, mp->ev[which][b], 0));
+    }
+}
+
+void multi_submit(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32) {
+    const size_t G = mp->shard.size();
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (zk_prover *q : mp->shard) locks.emplace_back(q->mtx);
+    zk_prover *p0 = mp->shard[0];
+    if (p0->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("three proofs already in flight: collect one first");
+    // the witness goes to every GPU (each needs all of it for its rows of A.w / B.w): staged ONCE into
+    // pinned memory (host function on shard 0's upload stream), then G DMA copies
+    const uint8_t *src = wtns;
+    hipEvent_t ready = nullptr;
+    {
+        hipPointerAttribute_t attr;
+        const bool pinned = hipPointerGetAttributes(&attr, wtns) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (!pinned && G > 1) {
+            const int k = (int)(mp->submitted % ZK_MAX_IN_FLIGHT);
+            const size_t bytes = (size_t)p0->nVars * 32;
+            DeviceGuard g(p0->device);
+            if (!mp->stage_pin[k]) HIP_TRY(hipHostMalloc((void **)&mp->stage_pin[k], bytes, hipHostMallocPortable));
+            mp->stage[k] = StageJob{mp->stage_pin[k], wtns, bytes};
+            HIP_TRY(hipLaunchHostFunc(p0->stream_h2d, stage_job_run, &mp->stage[k]));
+            HIP_TRY(hipEventRecord(mp->ev_staged[k], p0->stream_h2d));
+            src = mp->stage_pin[k];
+            ready = mp->ev_staged[k];
+        }
+    }
+    std::vector<PhaseAbort> guards;
+    guards.reserve(G);
+    for (zk_prover *q : mp->shard) guards.push_back(PhaseAbort{q});
+    if (!mp->part) {
+        for (zk_prover *q : mp->shard) {
+            phase_front(q, nullptr, src, r32, s32, ready);
+            phase_local(q);
+            phase_back(q);
+        }
+    } else {
+        for (size_t a = 0; a < G; a++) {
+            phase_front(mp->shard[a], nullptr, src, r32, s32, ready);
+            phase_cross_push(mp->shard[a], mp->ev[0][a]);
+        }
+        wait_all(mp, 0);
+        for (size_t a = 0; a < G; a++) phase_cross_run(mp->shard[a], true, mp->ev[1][a]);
+        wait_all(mp, 1);
+        for (size_t a = 0; a < G; a++) {
+            phase_local(mp->shard[a]);
+            phase_cross_push(mp->shard[a], mp->ev[2][a]);
+        }
+        wait_all(mp, 2);
+        for (size_t a = 0; a < G; a++) phase_cross_run(mp->shard[a], false, mp->ev[3][a]);
+        wait_all(mp, 3);
+        for (size_t a = 0; a < G; a++) phase_back(mp->shard[a]);
+    }
+    for (auto &gd : guards) gd.armed = false;
+    mp->submitted++;
+}
+
+void multi_collect(zk_multi_prover *mp, zk_proof *out) {
+    const size_t G = mp->shard.size();
+    std::vector<zk_msm_sums> sums(G);
+    uint8_t r32[32], s32[32];
+    bool have_r = false, have_s = false;
+    for (size_t a = 0; a < G; a++) {
+        zk_prover *q = mp->shard[a];
+        std::lock_guard<std::mutex> lk(q->mtx);
+        zk_prover::ProofSlot &sl = collect_sums_locked(q, &sums[a]);
+        if (a == 0) {
+            have_r = sl.have_r;
+            have_s = sl.have_s;
+            memcpy(r32, sl.r32, 32);
+            memcpy(s32, sl.s32, 32);
+        }
+    }
+    prove_finish(mp->shard[0], sums.data(), (uint32_t)G, have_r ? r32 : nullptr, have_s ? s32 : nullptr, out);
+}
+
+}   // namespace
+
+extern "C" {
+
+int zk_multi_prover_create(zk_multi_prover **out, const zk_zkey_view *zkey, const int32_t *devices, uint32_t n_devices, const zk_opts *opts) {
+    return guarded([&] { multi_create(out, zkey, devices, n_devices, opts); });
+}
+
+void zk_multi_prover_destroy(zk_multi_prover *mp) { delete mp; }
+
+int zk_multi_prove_submit(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32) {
+    return guarded([&] {
+        if (!mp || !wtns) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(mp->mtx);
+        multi_submit(mp, wtns, r32, s32);
+    });
+}
+
+int zk_multi_prove_collect(zk_multi_prover *mp, zk_proof *out) {
+    return guarded([&] {
+        if (!mp || !out) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(mp->mtx);
+        multi_collect(mp, out);
+    });
+}
+
+int zk_multi_prove(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
+    return guarded([&] {
+        if (!mp || !wtns || !out) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(mp->mtx);
+        if (mp->shard[0]->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
+        multi_submit(mp, wtns, r32, s32);
+        multi_collect(mp, out);
+    });
+}
+
+int zk_multi_prover_info(zk_multi_prover *mp, uint32_t *n_shards, uint32_t *chain_partitioned) {
+    return guarded([&] {
+        if (!mp) throw std::invalid_argument("null argument");
+        if (n_shards) *n_shards = (uint32_t)mp->shard.size();
+        if (chain_partitioned) *chain_partitioned = mp->part ? 1u : 0u;
+    });
+}
+
+int zk_shard_info(zk_prover *p, uint64_t *block_elems, uint32_t *chain_partitioned) {
+    return guarded([&] {
+        if (!p) throw std::invalid_argument("null argument");
+        if (block_elems) *block_elems = p->nloc;
+        if (chain_partitioned) *chain_partitioned = p->part ? 1u : 0u;
+    });
+}
+
+int zk_shard_set_exchange(zk_prover *p, void *d_abc, void *d_xb) {
+    return guarded([&] {
+        if (!p || !d_abc || !d_xb) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        if (!p->part) throw std::invalid_argument("prover was not created with ZK_FLAG_PARTITIONED_CHAIN");
+        if (p->in_flight || p->phase_open >= 0) throw std::invalid_argument("proofs in flight");
+        p->abc_use = (Fr *)d_abc;
+        p->xb_use = (Fr *)d_xb;
+        p->abc.release();
+        p->xb.release();
+    });
+}
+
+int zk_shard_begin(zk_prover *p, const uint8_t *wtns, const void *d_wtns, const uint8_t *r32, const uint8_t *s32, void *stream) {
+    return guarded([&] {
+        if (!p || (!wtns == !d_wtns)) throw std::invalid_argument("exactly one of wtns / d_wtns");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        if (!p->part) throw std::invalid_argument("prover was not created with ZK_FLAG_PARTITIONED_CHAIN");
+        DeviceGuard g(p->device);
+        PhaseAbort guard{p};
+        ext_in(p, stream);
+        phase_front(p, (const Fr *)d_wtns, wtns, r32, s32);
+        ext_out(p, stream);
+        guard.armed = false;
+    });
+}
+
+int zk_shard_step(zk_prover *p, int step, void *stream) {
+    return guarded([&] {
+        if (!p) throw std::invalid_argument("null argument");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        DeviceGuard g(p->device);
+        PhaseAbort guard{p};
+        ext_in(p, stream);
+        switch (step) {
+        case ZK_STEP_CROSS_INVERSE: phase_cross_run(p, true, nullptr); break;
+        case ZK_STEP_LOCAL: phase_local(p); break;
+        case ZK_STEP_CROSS_FORWARD: phase_cross_run(p, false, nullptr); break;
+        case ZK_STEP_FINISH: phase_back(p); break;
+        default: throw std::invalid_argument("unknown step");
+        }
+        ext_out(p, stream);
+        guard.armed = false;
     });
 }
 

@@ -43,13 +43,17 @@ class zk_msm_sums(C.Structure):
 
 ZK_FLAG_TIMINGS = 1
 ZK_FLAG_PRECOMP = 2
+ZK_FLAG_PARTITIONED_CHAIN = 4
+ZK_STEP_CROSS_INVERSE, ZK_STEP_LOCAL, ZK_STEP_CROSS_FORWARD, ZK_STEP_FINISH = 1, 2, 3, 4
 ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel", "wtns_h2d"]
 
 # every symbol include/zkhip.h declares (tests check the library exports all of them)
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
            "zk_prove_dev_submit", "zk_prove_submit", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
-           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble"]
+           "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble",
+           "zk_multi_prover_create", "zk_multi_prover_destroy", "zk_multi_prove", "zk_multi_prove_submit", "zk_multi_prove_collect",
+           "zk_multi_prover_info", "zk_shard_info", "zk_shard_set_exchange", "zk_shard_begin", "zk_shard_step"]
 
 
 def load_library():
@@ -60,6 +64,9 @@ def load_library():
     if not os.path.exists(path):
         raise ZkHipError("libzkhip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C rapidsnark-old_amd/csrc`; there is no CPU fallback" % path)
+    # six streams per prover: the HIP runtime's default of 4 hardware queues aliases them and the
+    # witness upload of proof k+1 then queues behind proof k (csrc/prover.hip); read at HIP init
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         # torch wheels bundle their own libamdhip64; load it FIRST so this process holds ONE HIP
         # runtime (two runtimes => the second one sees "No HIP GPUs are available").
@@ -87,6 +94,17 @@ def load_library():
     lib.zk_prove_finish.argtypes = [C.c_void_p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_assemble.argtypes = [u8p, u8p, u8p, u8p, u8p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_prover_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
+    lib.zk_multi_prover_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(zk_zkey_view), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(zk_opts)]
+    lib.zk_multi_prover_destroy.argtypes = [C.c_void_p]
+    lib.zk_multi_prover_destroy.restype = None
+    lib.zk_multi_prove.argtypes = [C.c_void_p, u8p, u8p, u8p, C.POINTER(zk_proof)]
+    lib.zk_multi_prove_submit.argtypes = [C.c_void_p, u8p, u8p, u8p]
+    lib.zk_multi_prove_collect.argtypes = [C.c_void_p, C.POINTER(zk_proof)]
+    lib.zk_multi_prover_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.zk_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.zk_shard_set_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.zk_shard_begin.argtypes = [C.c_void_p, u8p, C.c_void_p, u8p, u8p, C.c_void_p]
+    lib.zk_shard_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     for name in ("zk_fr_mul_vec", "zk_fq_mul_vec"):
         getattr(lib, name).argtypes = [u8p, u8p, u8p, C.c_uint64]
     lib.zk_fr_ntt.argtypes = [u8p, C.c_uint64, C.c_int]

@@ -12,32 +12,40 @@ from .wtns import load_wtns_header
 BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617   # main_prover.cpp:34
 
 
+def _zkey_view(zkey, keep):
+    """(header, zk_zkey_view) of a snarkjs .zkey given as path or bytes; `keep` collects the numpy views
+    the pointers refer to (main_prover.cpp:42-72)."""
+    f = open_existing(zkey, "zkey", 1)
+    h = load_zkey_header(f)
+    if h.rPrime != BN254_R:
+        raise ValueError("zkey curve not supported")            # main_prover.cpp:46-48
+    v = L.zk_zkey_view()
+    v.nVars, v.nPublic, v.domainSize, v.nCoefs = h.nVars, h.nPublic, h.domainSize, h.nCoefs
+
+    def ptr(b):
+        a = np.frombuffer(b, dtype=np.uint8)
+        keep.append(a)
+        return a.ctypes.data if a.size else None
+
+    v.vk_alpha1, v.vk_beta1, v.vk_beta2 = ptr(h.vk_alpha1), ptr(h.vk_beta1), ptr(h.vk_beta2)
+    v.vk_delta1, v.vk_delta2 = ptr(h.vk_delta1), ptr(h.vk_delta2)
+    for name, sec in (("coefs", 4), ("pointsA", 5), ("pointsB1", 6), ("pointsB2", 7), ("pointsC", 8), ("pointsH", 9)):
+        data = f.getSectionData(sec)                              # main_prover.cpp:67-72
+        setattr(v, name, ptr(data))
+        setattr(v, name + "_bytes", len(data))
+    return h, v
+
+
 class Prover:
-    def __init__(self, zkey, device=-1, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=False):
+    def __init__(self, zkey, device=-1, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=False,
+                 partitioned_chain=False):
         """zkey: path or bytes of a snarkjs .zkey (version <= 1, main_prover.cpp:42)."""
         self._lib = L.load_library()
-        f = open_existing(zkey, "zkey", 1)
-        h = load_zkey_header(f)
-        if h.rPrime != BN254_R:
-            raise ValueError("zkey curve not supported")            # main_prover.cpp:46-48
-        self.header = h
         self._keep = []
-        v = L.zk_zkey_view()
-        v.nVars, v.nPublic, v.domainSize, v.nCoefs = h.nVars, h.nPublic, h.domainSize, h.nCoefs
-
-        def ptr(b):
-            a = np.frombuffer(b, dtype=np.uint8)
-            self._keep.append(a)
-            return a.ctypes.data if a.size else None
-
-        v.vk_alpha1, v.vk_beta1, v.vk_beta2 = ptr(h.vk_alpha1), ptr(h.vk_beta1), ptr(h.vk_beta2)
-        v.vk_delta1, v.vk_delta2 = ptr(h.vk_delta1), ptr(h.vk_delta2)
-        for name, sec in (("coefs", 4), ("pointsA", 5), ("pointsB1", 6), ("pointsB2", 7), ("pointsC", 8), ("pointsH", 9)):
-            data = f.getSectionData(sec)                              # main_prover.cpp:67-72
-            setattr(v, name, ptr(data))
-            setattr(v, name + "_bytes", len(data))
+        self.header, v = _zkey_view(zkey, self._keep)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
-                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0))
+                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
+                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0))
         self._h = C.c_void_p()
         L.check(self._lib.zk_prover_create(C.byref(self._h), C.byref(v), C.byref(o)))
         self._keep = []     # host image may be released after create (include/zkhip.h)
@@ -102,11 +110,13 @@ class Prover:
             raise ValueError("witness size mismatch")
         (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
         L.check(self._lib.zk_prove_submit(self._h, C.c_void_p(a.ctypes.data), rp, sp))
+        self._pending = getattr(self, "_pending", []) + [a]      # the library reads it until the proof is collected
 
     def collect(self):
         """-> proof bytes of the OLDEST submitted proof (zk_prove_collect)."""
         out = L.zk_proof()
         L.check(self._lib.zk_prove_collect(self._h, C.byref(out)))
+        self._pending = getattr(self, "_pending", [])[1:]
         return bytes(out)
 
     def collect_msm(self):
@@ -137,6 +147,57 @@ class Prover:
         ms = (C.c_double * len(L.ZK_T_NAMES))()
         L.check(self._lib.zk_prover_timings(self._h, ms, len(L.ZK_T_NAMES)))
         return dict(zip(L.ZK_T_NAMES, list(ms)))
+
+
+class MultiProver:
+    """One proof on several GPUs of this process (zk_multi_prover): every MSM table sharded by point
+    range, the A.w/B.w rows and the six transforms partitioned the same way (2, 4 or 8 devices), partial
+    sums added on the host.  devices may repeat an ordinal (all shards on one GPU: test boxes)."""
+
+    def __init__(self, zkey, devices, window_bits=0, precomp=False):
+        self._lib = L.load_library()
+        keep = []
+        self.header, v = _zkey_view(zkey, keep)
+        devs = (C.c_int32 * len(devices))(*devices)
+        o = L.zk_opts(-1, 0, 1, window_bits, L.ZK_FLAG_PRECOMP if precomp else 0)
+        self._h = C.c_void_p()
+        L.check(self._lib.zk_multi_prover_create(C.byref(self._h), C.byref(v), devs, len(devices), C.byref(o)))
+        ns, part = C.c_uint32(), C.c_uint32()
+        L.check(self._lib.zk_multi_prover_info(self._h, C.byref(ns), C.byref(part)))
+        self.n_shards, self.chain_partitioned = ns.value, bool(part.value)
+        self._pending = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.zk_multi_prover_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _vals(self, wtns):
+        a = wtns if isinstance(wtns, np.ndarray) else Prover._wtns_values(self, wtns)
+        if a.size != self.header.nVars * 32:
+            raise ValueError("witness size mismatch")
+        return a
+
+    def prove(self, wtns, r=None, s=None):
+        a = self._vals(wtns)
+        (ra, rp), (sa, sp) = Prover._rs(r), Prover._rs(s)
+        out = L.zk_proof()
+        L.check(self._lib.zk_multi_prove(self._h, C.c_void_p(a.ctypes.data), rp, sp, C.byref(out)))
+        return bytes(out)
+
+    def submit(self, wtns, r=None, s=None):
+        a = self._vals(wtns)
+        (ra, rp), (sa, sp) = Prover._rs(r), Prover._rs(s)
+        L.check(self._lib.zk_multi_prove_submit(self._h, C.c_void_p(a.ctypes.data), rp, sp))
+        self._pending.append(a)
+
+    def collect(self):
+        out = L.zk_proof()
+        L.check(self._lib.zk_multi_prove_collect(self._h, C.byref(out)))
+        self._pending = self._pending[1:]
+        return bytes(out)
 
 
 def prove_files(zkey_path, wtns_path, proof_path, public_path, r=None, s=None):

@@ -1,0 +1,141 @@
+"""One proof on several GPUs with the chain PARTITIONED across them (north_star: "the five
+MSMs and the NTT partitioned across the 8 GPUs"), exercised on the ONE GPU of the test box: every shard
+prover lives on device 0, so the peer writes / cross-device events of zk_multi_prover become same-device
+copies and waits, and the all_to_all of the one-process-per-GPU path (zk_shard_*) is played by tensor
+copies between the shards' exchange buffers.  Results must be the golden / single-GPU proofs bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden_bytes, golden_json, golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["r1cs_n64", "r1cs_n256"])
+@pytest.mark.parametrize("shards", [2, 3, 4, 8])
+@pytest.mark.parametrize("precomp", [False, True])
+def test_multi_prover_equals_golden(zk, name, shards, precomp):
+    """zk_multi_prove: 2/4/8 shards partition the chain (cross stages of 1/2/3 index bits), 3 shards fall
+    back to the replicated chain; same proof bytes either way."""
+    meta = golden_json(name, "meta.json")
+    mp = zk.MultiProver(golden_path(name, "circuit.zkey"), [0] * shards, precomp=precomp)
+    assert mp.n_shards == shards and mp.chain_partitioned == (shards in (2, 4, 8))
+    wt = golden_bytes(name, "witness.wtns")
+    for _ in range(2):
+        assert mp.prove(wt, r=int(meta["r"]), s=int(meta["s"])).hex() == meta["proof_bytes"]
+    mp.close()
+
+
+def test_multi_prover_pipeline_and_nopub(zk):
+    """submit/collect with three proofs in flight on four shards; nPublic = 0 fixture."""
+    name = "r1cs_n256"
+    single = zk.Prover(golden_path(name, "circuit.zkey"))
+    base = np.array(single._wtns_values(golden_bytes(name, "witness.wtns")), dtype=np.uint8)
+    mp = zk.MultiProver(golden_path(name, "circuit.zkey"), [0, 0, 0, 0], precomp=True)
+    hosts, want, rs = [], [], [(21 + i, 900 + 5 * i) for i in range(7)]
+    for i, (r, s) in enumerate(rs):
+        w = base.copy()
+        w[32 * (3 + i)] ^= 0x11
+        hosts.append(w)
+        want.append(single.prove(w.tobytes(), r, s))
+    got = []
+    for i, (r, s) in enumerate(rs):
+        if i >= 3:
+            got.append(mp.collect())
+        mp.submit(hosts[i], r, s)
+    got += [mp.collect(), mp.collect(), mp.collect()]
+    assert got == want
+    with pytest.raises(zk.ZkHipError):
+        mp.collect()
+    mp.close()
+    single.close()
+    meta = golden_json("r1cs_nopub", "meta.json")
+    mp = zk.MultiProver(golden_path("r1cs_nopub", "circuit.zkey"), [0, 0])
+    assert mp.prove(golden_bytes("r1cs_nopub", "witness.wtns"), r=int(meta["r"]), s=int(meta["s"])).hex() == meta["proof_bytes"]
+    mp.close()
+
+
+@pytest.mark.parametrize("k,shards", [(12, 8), (16, 4), (20, 8)])
+def test_partitioned_chain_at_scale(zk, tmp_path, k, shards):
+    """Synthetic family: the partitioned chain (local pass plans of 2^(k - log2 G) blocks + cross stages)
+    against the unsharded prover, on a .zkey file written to disk; precomputed tables on the shards."""
+    import torch
+    from oracle import c_oracle as co
+    from rapidsnark_old_amd import synth
+    from test_gpu_synth import _write_synth_files
+    wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes())
+    w = synth.make_witness(k, seed=4)
+    zpath, wpath, _ = _write_synth_files(tmp_path, wl, w)
+    r, s = 0x5555AAAA, (1 << 245) + 3
+    single = zk.Prover(zpath)
+    want = single.prove(w, r, s)
+    single.close()
+    mp = zk.MultiProver(zpath, [0] * shards, precomp=True)
+    assert mp.chain_partitioned
+    assert mp.prove(w, r, s) == want
+    mp.submit(w, r, s)
+    mp.submit(w, r, s)
+    assert mp.collect() == want and mp.collect() == want
+    mp.close()
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_shard_step_api_with_emulated_all_to_all(zk, shards):
+    """zk_shard_begin / zk_shard_step as a one-process-per-GPU job drives them (rapidsnark_old_amd.dist.
+    ShardedChain), with dist.all_to_all_single played by copies between the ranks' registered buffers:
+    rank r receives chunk r of every rank's block."""
+    import torch
+    from rapidsnark_old_amd import lib as L
+    from rapidsnark_old_amd.dist import ShardedChain
+    name = "r1cs_n256"
+    meta = golden_json(name, "meta.json")
+    provers = [zk.Prover(golden_path(name, "circuit.zkey"), shard_index=i, shard_count=shards, partitioned_chain=True) for i in range(shards)]
+    wt = np.array(provers[0]._wtns_values(golden_bytes(name, "witness.wtns")), dtype=np.uint8)
+    chains = []
+
+    def make_exchange(rank):
+        def exchange(dst, src):            # called per rank in lock-step below: only stage this rank's request
+            pending.append((rank, dst, src))
+        return exchange
+
+    pending = []
+    for i, p in enumerate(provers):
+        chains.append(ShardedChain(p._lib, p._h, None, torch.device("cuda:0"), exchange=make_exchange(i)))
+
+    def run_all_to_all():
+        torch.cuda.synchronize()
+        reqs = sorted(pending, key=lambda t: t[0])
+        assert [t[0] for t in reqs] == list(range(shards))
+        srcs = [t[2].clone() for t in reqs]
+        for rnk, dst, _ in reqs:
+            for poly in range(3):
+                ch = dst.shape[1] // shards
+                for sidx in range(shards):
+                    dst[poly, sidx * ch:(sidx + 1) * ch] = srcs[sidx][poly, rnk * ch:(rnk + 1) * ch]
+        torch.cuda.synchronize()
+        pending.clear()
+
+    # drive the ranks in lock-step: each phase of every rank, then the exchange
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for ch, p in zip(chains, provers):
+        L.check(p._lib.zk_shard_begin(p._h, C.c_void_p(wt.ctypes.data), None, None, None, stream))
+        ch.exchange(ch.xb, ch.abc)
+    run_all_to_all()
+    for step, (dst, src) in ((L.ZK_STEP_CROSS_INVERSE, ("abc", "xb")), (L.ZK_STEP_LOCAL, ("xb", "abc")), (L.ZK_STEP_CROSS_FORWARD, ("abc", "xb"))):
+        for ch, p in zip(chains, provers):
+            L.check(p._lib.zk_shard_step(p._h, step, stream))
+            ch.exchange(getattr(ch, dst), getattr(ch, src))
+        run_all_to_all()
+    parts = []
+    for ch, p in zip(chains, provers):
+        L.check(p._lib.zk_shard_step(p._h, L.ZK_STEP_FINISH, stream))
+        parts.append(p.collect_msm())
+    proof = provers[0].prove_finish(parts, r=int(meta["r"]), s=int(meta["s"]))
+    assert proof.hex() == meta["proof_bytes"]
+    # a partitioned prover refuses the one-call entry points
+    with pytest.raises(zk.ZkHipError):
+        provers[0].prove_msm(wt.tobytes())
+    for p in provers:
+        p.close()
