@@ -302,7 +302,7 @@ def plan_window_bits(n, world, precomp):
 class ProverFromView:
     """zk.Prover over an in-memory view (numpy arrays) instead of a .zkey file."""
 
-    def __init__(self, zk, wl, device, shard_index, shard_count, window_bits, timings, precomp=False):
+    def __init__(self, zk, wl, device, shard_index, shard_count, window_bits, timings, precomp=False, partitioned_chain=False):
         import ctypes as C
         from rapidsnark_old_amd import lib as L
         self.L = L
@@ -318,7 +318,8 @@ class ProverFromView:
             if hasattr(v, name + "_bytes"):
                 setattr(v, name + "_bytes", a.size)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
-                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0))
+                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
+                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0))
         self.h = C.c_void_p()
         L.check(self.lib.zk_prover_create(C.byref(self.h), C.byref(v), C.byref(o)))
         self.keep = []

@@ -15,14 +15,28 @@
 //     form); HBM keeps canonical 256-bit words in the 2^261 Montgomery form, LDS holds 9 limb planes
 //     (72 KiB per 2048-element tile); the coset*1/n table is applied as the first DIT pass loads.
 // The butterflies are Montgomery-multiply bound (VALU), see DESIGN.md.
+#include <stdlib.h>
 #include "kernels.hpp"
 #include "hipcheck.hpp"
 #include "field29.hpp"
 
 namespace zk {
 
-#define NTT_THREADS 512
+// Workgroup shape of a pass.  The tile (2^11 elements = 72 KiB of LDS) sets how many stages one launch
+// covers; the thread count sets what the pass can run BESIDE: a 512-thread workgroup needs two waves
+// of 104 VGPRs on every SIMD of its CU at once, which never fits next to the resident bucket-accumulation
+// waves (G1: 3 x 136 of the 512 registers, G2 split-lane: 2 x 200), so the chain only advanced in the
+// gaps between MSM kernels; 256 threads = one wave per SIMD does fit (ZKHIP_NTT_THREADS / ZKHIP_NTT_TILE
+// override, tuning aids).
 #define NTT_MAX_TILE_LOG 11
+static uint32_t ntt_threads() {
+    static const uint32_t v = [] { const char *e = getenv("ZKHIP_NTT_THREADS"); uint32_t t = e ? (uint32_t)atoi(e) : 256u; return t == 512u ? 512u : 256u; }();
+    return v;
+}
+static uint32_t ntt_tile_log() {
+    static const uint32_t v = [] { const char *e = getenv("ZKHIP_NTT_TILE"); uint32_t t = e ? (uint32_t)atoi(e) : 10u; return t < 8u ? 8u : (t > 11u ? 11u : t); }();
+    return v;
+}
 
 template <class F>
 __device__ __forceinline__ F load_el(const F *p) {
@@ -75,7 +89,7 @@ __device__ __forceinline__ void store_tw(TwEntry *e, const Fr29 &v) {       // v
     q[2] = make_uint4((uint32_t)v.l[8], 0u, 0u, 0u);
 }
 
-template <bool DIF>
+template <bool DIF, int NTT_THREADS>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(Fr *data, uint64_t stride_elems, const TwEntry *tw, const Fr *premul,
                                                           uint32_t logn, uint32_t lo, uint32_t t, uint32_t q) {
     extern __shared__ int32_t lds[];
@@ -148,7 +162,8 @@ struct PassPlan {
 static PassPlan plan_passes(uint32_t logn) {
     PassPlan p;
     p.n = 0;
-    uint32_t t0 = logn < NTT_MAX_TILE_LOG ? logn : NTT_MAX_TILE_LOG;
+    const uint32_t TL = ntt_tile_log();
+    uint32_t t0 = logn < TL ? logn : TL;
     p.lo[0] = 0; p.t[0] = t0; p.q[0] = 0; p.n = 1;
     uint32_t rem = logn - t0;
     if (rem) {
@@ -156,7 +171,7 @@ static PassPlan plan_passes(uint32_t logn) {
         uint32_t lo = t0;
         for (uint32_t i = 0; i < k; i++) {
             uint32_t t = rem / (k - i) + ((rem % (k - i)) ? 1 : 0);
-            uint32_t q = NTT_MAX_TILE_LOG - t;
+            uint32_t q = TL - t;
             if (q > lo) q = lo;
             p.lo[p.n] = lo; p.t[p.n] = t; p.q[p.n] = q; p.n++;
             lo += t;
@@ -176,11 +191,16 @@ static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *t
     size_t shmem = (size_t)36 << T;     // 9 limb planes; 72 KiB at T = 11 (opt-in above 64 KiB)
     static bool attr_set = false;
     if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_ntt_pass<DIF>, dim3(tiles, batch), dim3(NTT_THREADS), shmem, s, data, stride, tw, premul, logn, lo, t, q);
+    if (ntt_threads() == 512u)
+        hipLaunchKernelGGL((k_ntt_pass<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, tw, premul, logn, lo, t, q);
+    else
+        hipLaunchKernelGGL((k_ntt_pass<DIF, 256>), dim3(tiles, batch), dim3(256), shmem, s, data, stride, tw, premul, logn, lo, t, q);
     ZK_LAUNCH_OK("ntt pass");
 }
 

@@ -1,21 +1,28 @@
 #include "fullprover.hpp"
 
-#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <spawn.h>
 #include <stdexcept>
 #include <sys/wait.h>
-#include <thread>
+#include <unistd.h>
 
 #include "json_min.hpp"
 
-static const uint8_t kAltBn128r[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
-                                       0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+extern char **environ;
 
-static bool env_scalar(const char *name, uint8_t out[32]) {
+namespace {
+
+// BN254 scalar field order, little-endian (the reference compares decimal strings, src/fullprover.cpp:31-35)
+const uint8_t kBn254Order[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+                                 0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+
+// ZKHIP_FIXED_R / ZKHIP_FIXED_S (64 hex digits, LE): deterministic proofs for parity tests
+bool scalarFromEnv(const char *name, uint8_t out[32]) {
     const char *v = getenv(name);
     if (!v || strlen(v) != 64) return false;
     for (int i = 0; i < 32; i++) {
@@ -26,145 +33,326 @@ static bool env_scalar(const char *name, uint8_t out[32]) {
     return true;
 }
 
-static std::string getfilename(std::string path) {   // file stem = circuit name (fullprover.cpp:14-19)
-    path = path.substr(path.find_last_of("/\\") + 1);
-    return path.substr(0, path.find_last_of('.'));
+// The witness generator hand-off of the reference (src/fullprover.cpp:112-135): run
+//   ./build/<circuit> <input.json> <out.wtns>
+// with its standard output captured, echo the output and the raw wait status like the reference does,
+// and (unlike it, quirk Q11) fail the job on a non-zero exit.  posix_spawn instead of popen: no shell
+// between the server and the generator.
+int runGenerator(const std::string &exe, const std::string &inputFile, const std::string &witnessFile, std::string &captured) {
+    int fds[2];
+    if (pipe(fds) != 0) throw std::runtime_error("Couldn't start command.");
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, fds[1], STDOUT_FILENO);
+    posix_spawn_file_actions_addclose(&fa, fds[0]);
+    posix_spawn_file_actions_addclose(&fa, fds[1]);
+    std::string a0 = exe, a1 = inputFile, a2 = witnessFile;
+    char *argv[] = {a0.data(), a1.data(), a2.data(), nullptr};
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, exe.c_str(), &fa, nullptr, argv, environ);
+    posix_spawn_file_actions_destroy(&fa);
+    close(fds[1]);
+    if (rc != 0) {
+        close(fds[0]);
+        throw std::runtime_error("Couldn't start command.");
+    }
+    char chunk[4096];
+    for (ssize_t k; (k = read(fds[0], chunk, sizeof chunk)) > 0;) captured.append(chunk, (size_t)k);
+    close(fds[0]);
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+    }
+    return status;
 }
 
+std::vector<int> workerDevicesFromEnv() {
+    const char *w = getenv("ZKHIP_WORKERS");
+    if (!w || !*w) return {-1};                       // one replica on ZKHIP_DEVICE / ZKHIP_DEVICES / the current device
+    if (std::string(w) == "all") {
+        int n = 0;
+        if (zk_device_count(&n) != 0 || n <= 0) throw std::runtime_error(zk_last_error());
+        std::vector<int> v;
+        for (int i = 0; i < n; i++) v.push_back(i);
+        return v;
+    }
+    std::vector<int> v;
+    for (int32_t d : Groth16::parseDeviceList(w)) v.push_back(d);
+    return v;
+}
+
+}   // namespace
+
 FullProver::FullProver(std::string zkeyFileNames[], int size) {
+    workerDevices = workerDevicesFromEnv();
+    if (const char *q = getenv("ZKHIP_QUEUE")) queueCap = (size_t)strtoul(q, nullptr, 10);
     for (int i = 0; i < size; i++) {
-        std::string circuit = getfilename(zkeyFileNames[i]);
+        const std::string circuit = std::filesystem::path(zkeyFileNames[i]).stem().string();   // circuit name = file stem (fullprover.cpp:14-19,25)
         auto zkey = BinFileUtils::openExisting(zkeyFileNames[i], "zkey", 1);
         auto hdr = ZKeyUtils::loadHeader(zkey.get());
-        if (memcmp(hdr->rPrime.data(), kAltBn128r, 32) != 0) throw std::invalid_argument("zkey curve not supported");
+        if (memcmp(hdr->rPrime.data(), kBn254Order, 32) != 0) throw std::invalid_argument("zkey curve not supported");
         const uint64_t sizes[6] = {zkey->getSectionSize(4), zkey->getSectionSize(5), zkey->getSectionSize(6),
                                    zkey->getSectionSize(7), zkey->getSectionSize(8), zkey->getSectionSize(9)};
-        circuits[circuit].prover = Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
-                                               hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
-                                               zkey->getSectionData(5), zkey->getSectionData(6), zkey->getSectionData(7),
-                                               zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true);
+        Circuit &c = circuits[circuit];
+        for (int dev : workerDevices)
+            c.replica.push_back(Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
+                                                    hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
+                                                    zkey->getSectionData(5), zkey->getSectionData(6), zkey->getSectionData(7),
+                                                    zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true, dev));
         // libzkhip copied everything it needs to the GPU: only the scalar header fields are kept
         // (the vk pointers into the mapping die with `zkey` and are never used again here)
         hdr->vk_alpha1 = hdr->vk_beta1 = hdr->vk_beta2 = hdr->vk_gamma2 = hdr->vk_delta1 = hdr->vk_delta2 = nullptr;
-        circuits[circuit].header = std::move(hdr);
+        c.header = std::move(hdr);
         std::cerr << "circuit: " << circuit << '\n';
     }
-    status = ready;
+    if (queueMode()) {
+        size_t nw = 4;
+        if (const char *t = getenv("ZKHIP_WITNESS_THREADS")) nw = (size_t)strtoul(t, nullptr, 10);
+        if (nw == 0) nw = 1;
+        for (size_t i = 0; i < nw; i++) threads.emplace_back(&FullProver::witnessLoop, this);
+        for (size_t w = 0; w < workerDevices.size(); w++) threads.emplace_back(&FullProver::deviceLoop, this, w);
+        std::cerr << "throughput mode: queue " << queueCap << ", " << workerDevices.size() << " GPU worker(s), " << nw << " witness thread(s)\n";
+    }
 }
 
+FullProver::~FullProver() {
+    {
+        std::lock_guard<std::mutex> guard(mtx);
+        stopping = true;
+    }
+    cvIncoming.notify_all();
+    cvReady.notify_all();
+    for (auto &t : threads) t.join();
+}
+
+// Everything between the request body and the call of prove(): input file, generator, witness image,
+// public signals (src/fullprover.cpp:104-152).  `tag` distinguishes the files of concurrent jobs; it is
+// empty in single-slot mode, where the paths are exactly the reference's.
+void FullProver::generateWitness(Job &job, const std::string &tag) {
+    if (!JsonMin::isValid(job.input)) throw std::runtime_error("input is not valid JSON");
+    auto known = circuits.find(job.circuit);
+    if (known == circuits.end()) throw std::runtime_error("unknown circuit: " + job.circuit);
+    const std::string base = "./build/";
+    const std::string inputFile = base + "input_" + job.circuit + tag + ".json";
+    const std::string witnessFile = base + job.circuit + tag + ".wtns";
+    {
+        std::ofstream f(inputFile);
+        f << job.input;
+    }
+    std::string output;
+    const int waitStatus = runGenerator(base + job.circuit, inputFile, witnessFile, output);
+    std::cout << output << std::endl;
+    std::cout << waitStatus << std::endl;
+    if (waitStatus != 0)
+        throw std::runtime_error("witness generator failed with code " + std::to_string(WIFEXITED(waitStatus) ? WEXITSTATUS(waitStatus) : waitStatus));
+
+    job.wtns = BinFileUtils::openExisting(witnessFile, "wtns", 2);
+    auto wh = WtnsUtils::loadHeader(job.wtns.get());
+    if (memcmp(wh->prime.data(), kBn254Order, 32) != 0) throw std::invalid_argument("different wtns curve");
+    const ZKeyUtils::Header *zh = known->second.header.get();
+    if (wh->nVars != zh->nVars || job.wtns->getSectionSize(2) < (uint64_t)zh->nVars * 32)
+        throw std::invalid_argument("witness does not match the zkey (nVars)");
+    job.wtnsData = static_cast<const uint8_t *>(job.wtns->getSectionData(2));
+    std::string pub(zk_public_to_json(job.wtnsData, zh->nPublic, nullptr, 0), '\0');
+    zk_public_to_json(job.wtnsData, zh->nPublic, pub.data(), pub.size() + 1);
+    job.pubData = pub;
+    if (!tag.empty()) {      // concurrent jobs: the mapping keeps the witness alive, the names can go
+        std::remove(inputFile.c_str());
+        std::remove(witnessFile.c_str());
+    }
+}
+
+// ------------------------------------------------------------------ single-slot mode (the reference's)
 void FullProver::startProve(std::string input, std::string circuit) {
     std::lock_guard<std::mutex> guard(mtx);
-    pending = Job{input, circuit};
-    if (status == busy) canceled = true;   // reference: abort() here re-locks mtx and deadlocks (Q2)
+    pending = std::make_shared<Job>();
+    pending->input = std::move(input);
+    pending->circuit = std::move(circuit);
+    if (status == busy && executing) executing->canceled = true;   // reference: abort() here re-locks mtx and deadlocks (Q2)
     checkPending();
 }
 
 void FullProver::checkPending() {
-    if (status == busy) return;
-    if (pending.empty()) return;
+    if (status == busy || !pending) return;
+    if (pending->input.empty() || pending->circuit.empty()) return;
     status = busy;
     executing = pending;
-    pending.clear();
-    errString.clear();
-    canceled = false;
-    proof = "null";
-    std::thread th(&FullProver::thread_calculateProve, this);
-    th.detach();
+    pending.reset();
+    std::thread(&FullProver::runSingle, this, executing).detach();
 }
 
-void FullProver::thread_calculateProve() {
+void FullProver::runSingle(JobPtr job) {
+    std::string proofJson = "null", error;
     try {
-        std::string input, circuit;
+        generateWitness(*job, "");
+        bool run;
         {
             std::lock_guard<std::mutex> guard(mtx);
-            input = executing.input;
-            circuit = executing.circuit;
+            run = !job->canceled;
         }
-        if (!JsonMin::isValid(input)) throw std::runtime_error("input is not valid JSON");
-        auto pit = circuits.find(circuit);
-        if (pit == circuits.end()) throw std::runtime_error("unknown circuit: " + circuit);
-
-        // witness generation: the exact hand-off of fullprover.cpp:112-135 (same paths, same argv)
-        {
-            std::ofstream file("./build/input_" + circuit + ".json");
-            file << input;
-        }
-        std::string witnessFile("./build/" + circuit + ".wtns");
-        std::string command("./build/" + circuit + " ./build/input_" + circuit + ".json " + witnessFile);
-        std::array<char, 128> buffer;
-        std::string result;
-        FILE *pipe = popen(command.c_str(), "r");
-        if (!pipe) throw std::runtime_error("Couldn't start command.");
-        while (fgets(buffer.data(), 128, pipe) != NULL) result += buffer.data();
-        int returnCode = pclose(pipe);
-        std::cout << result << std::endl;
-        std::cout << returnCode << std::endl;
-        if (returnCode != 0) throw std::runtime_error("witness generator failed with code " + std::to_string(WEXITSTATUS(returnCode)));
-
-        auto wtns = BinFileUtils::openExisting(witnessFile, "wtns", 2);
-        auto wtnsHeader = WtnsUtils::loadHeader(wtns.get());
-        if (memcmp(wtnsHeader->prime.data(), kAltBn128r, 32) != 0) throw std::invalid_argument("different wtns curve");
-        const ZKeyUtils::Header *zh = pit->second.header.get();
-        if (wtnsHeader->nVars != zh->nVars || wtns->getSectionSize(2) < (uint64_t)zh->nVars * 32)
-            throw std::invalid_argument("witness does not match the zkey (nVars)");
-        const uint8_t *wtnsData = static_cast<const uint8_t *>(wtns->getSectionData(2));
-
-        size_t n = zk_public_to_json(wtnsData, zh->nPublic, nullptr, 0);
-        std::string pub(n + 1, '\0');
-        zk_public_to_json(wtnsData, zh->nPublic, &pub[0], n + 1);
-        pub.resize(n);
-
-        // ZKHIP_FIXED_R / ZKHIP_FIXED_S (64 hex digits, LE): deterministic proofs for parity tests
         uint8_t r[32], s[32];
-        bool fr = env_scalar("ZKHIP_FIXED_R", r), fs = env_scalar("ZKHIP_FIXED_S", s);
-        std::string pr = "null";
-        if (!isCanceled()) pr = pit->second.prover->prove(wtnsData, fr ? r : nullptr, fs ? s : nullptr)->toJson();   // HOT PATH (fullprover.cpp:155)
-        {
-            std::lock_guard<std::mutex> guard(mtx);
-            pubData = pub;
-            proof = pr;
-        }
-        calcFinished();
+        const bool haveR = scalarFromEnv("ZKHIP_FIXED_R", r), haveS = scalarFromEnv("ZKHIP_FIXED_S", s);
+        if (run) proofJson = circuits[job->circuit].replica[0]->prove(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr)->toJson();   // HOT PATH (fullprover.cpp:155)
     } catch (std::exception &e) {   // reference catches runtime_error only: a JSON error kills it (Q3)
-        if (!isCanceled()) {
-            std::lock_guard<std::mutex> guard(mtx);
-            errString = e.what();
-        }
-        calcFinished();
+        error = e.what();
     }
-}
-
-void FullProver::calcFinished() {
     std::lock_guard<std::mutex> guard(mtx);
-    if (canceled) status = aborted;
-    else if (!errString.empty()) status = failed;
-    else status = success;
-    canceled = false;
-    executing.clear();
+    job->wtns.reset();
+    job->proof = proofJson;
+    job->error = job->canceled ? "" : error;
+    job->status = job->canceled ? aborted : (!error.empty() ? failed : success);
+    status = job->status;
+    last = job;
+    executing.reset();
     checkPending();
-}
-
-bool FullProver::isCanceled() {
-    std::lock_guard<std::mutex> guard(mtx);
-    return canceled;
 }
 
 void FullProver::abort() {
     std::lock_guard<std::mutex> guard(mtx);
-    if (status != busy) return;
-    canceled = true;
+    if (queueMode()) {           // cancels everything that has not reached a GPU yet
+        for (auto &j : incoming) {
+            j->status = aborted;
+            j->canceled = true;
+        }
+        incoming.clear();
+        return;
+    }
+    if (status == busy && executing) executing->canceled = true;
 }
 
 // Same documents as nlohmann's dump() of FullProver::getStatus (fullprover.cpp:216-240): keys in
 // alphabetical order, compact; proof and pubData are STRINGS containing JSON.
-std::string FullProver::getStatus() {
-    std::lock_guard<std::mutex> guard(mtx);
-    switch (status) {
+std::string FullProver::statusDocument(const Job &job) {
+    switch (job.status) {
         case ready: return "{\"status\":\"ready\"}";
         case aborted: return "{\"status\":\"aborted\"}";
-        case failed: return "{\"error\":" + JsonMin::quote(errString) + ",\"status\":\"failed\"}";
-        case success: return "{\"proof\":" + JsonMin::quote(proof) + ",\"pubData\":" + JsonMin::quote(pubData) + ",\"status\":\"success\"}";
+        case failed: return "{\"error\":" + JsonMin::quote(job.error) + ",\"status\":\"failed\"}";
+        case success: return "{\"proof\":" + JsonMin::quote(job.proof) + ",\"pubData\":" + JsonMin::quote(job.pubData) + ",\"status\":\"success\"}";
         case busy: return "{\"status\":\"busy\"}";
     }
     return "{}";
+}
+
+std::string FullProver::getStatus() {
+    std::lock_guard<std::mutex> guard(mtx);
+    if (queueMode()) {
+        if (jobs.empty()) return "{\"status\":\"ready\"}";
+        return statusDocument(*jobs.rbegin()->second);
+    }
+    if (status == busy) return "{\"status\":\"busy\"}";
+    if (status == ready || !last) return "{\"status\":\"ready\"}";
+    return statusDocument(*last);
+}
+
+// ------------------------------------------------------------------ throughput mode
+bool FullProver::enqueue(std::string input, std::string circuit, uint64_t &id) {
+    std::lock_guard<std::mutex> guard(mtx);
+    if (incoming.size() >= queueCap) return false;
+    JobPtr j = std::make_shared<Job>();
+    j->id = id = nextId++;
+    j->input = std::move(input);
+    j->circuit = std::move(circuit);
+    incoming.push_back(j);
+    remember(j);
+    cvIncoming.notify_one();
+    return true;
+}
+
+void FullProver::remember(const JobPtr &job) {
+    jobs[job->id] = job;
+    while (jobs.size() > 4096) jobs.erase(jobs.begin());
+}
+
+std::string FullProver::getStatus(uint64_t id) {
+    std::lock_guard<std::mutex> guard(mtx);
+    auto it = jobs.find(id);
+    if (it == jobs.end()) return "{\"error\":\"unknown job\",\"status\":\"failed\"}";
+    return statusDocument(*it->second);
+}
+
+// host side of the pipeline: witness generators of later jobs run while earlier proofs are on the GPUs
+void FullProver::witnessLoop() {
+    for (;;) {
+        JobPtr job;
+        {
+            std::unique_lock<std::mutex> lk(mtx);
+            cvIncoming.wait(lk, [&] { return stopping || !incoming.empty(); });
+            if (stopping) return;
+            job = incoming.front();
+            incoming.pop_front();
+        }
+        std::string error;
+        try {
+            generateWitness(*job, "." + std::to_string(job->id));
+        } catch (std::exception &e) {
+            error = e.what();
+        }
+        std::lock_guard<std::mutex> guard(mtx);
+        if (!error.empty()) {
+            job->wtns.reset();
+            job->error = error;
+            job->status = failed;
+            continue;
+        }
+        readyJobs.push_back(job);
+        cvReady.notify_one();
+    }
+}
+
+// one per GPU: keeps up to ZK_MAX_IN_FLIGHT proofs in flight on its replicas (a collect returns the
+// oldest proof of THAT prover, so in-flight jobs are tracked per circuit)
+void FullProver::deviceLoop(size_t worker) {
+    std::map<std::string, std::deque<JobPtr>> flying;
+    size_t nflying = 0;
+    uint8_t r[32], s[32];
+    const bool haveR = scalarFromEnv("ZKHIP_FIXED_R", r), haveS = scalarFromEnv("ZKHIP_FIXED_S", s);
+    auto finishOldest = [&](const std::string &circuit) {
+        std::deque<JobPtr> &q = flying[circuit];
+        JobPtr job = q.front();
+        q.pop_front();
+        nflying--;
+        std::string proofJson, error;
+        try {
+            proofJson = circuits[circuit].replica[worker]->collect()->toJson();
+        } catch (std::exception &e) {
+            error = e.what();
+        }
+        std::lock_guard<std::mutex> guard(mtx);
+        job->wtns.reset();
+        job->proof = error.empty() ? proofJson : "null";
+        job->error = error;
+        job->status = error.empty() ? success : failed;
+    };
+    for (;;) {
+        JobPtr job;
+        {
+            std::unique_lock<std::mutex> lk(mtx);
+            if (nflying == 0) cvReady.wait(lk, [&] { return stopping || !readyJobs.empty(); });
+            if (stopping && nflying == 0) return;
+            if (!readyJobs.empty()) {
+                job = readyJobs.front();
+                readyJobs.pop_front();
+            }
+        }
+        if (job) {
+            // a prover holds at most ZK_MAX_IN_FLIGHT proofs: make room on that circuit's replica first
+            while (flying[job->circuit].size() >= ZK_MAX_IN_FLIGHT) finishOldest(job->circuit);
+            try {
+                circuits[job->circuit].replica[worker]->submit(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr);
+                flying[job->circuit].push_back(job);
+                nflying++;
+            } catch (std::exception &e) {
+                std::lock_guard<std::mutex> guard(mtx);
+                job->wtns.reset();
+                job->error = e.what();
+                job->status = failed;
+            }
+            continue;                // look for more work before blocking in a collect
+        }
+        // nothing new is ready: retire the oldest proof in flight (any circuit)
+        for (auto &kv : flying)
+            if (!kv.second.empty()) {
+                finishOldest(kv.first);
+                break;
+            }
+    }
 }

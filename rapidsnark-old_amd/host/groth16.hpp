@@ -10,6 +10,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/zkhip.h"
 
@@ -29,10 +30,15 @@ public:
 
 class Prover {
     zk_prover *h_ = nullptr;
+    zk_multi_prover *m_ = nullptr;      // ZKHIP_DEVICES=0,1,...: one proof split over several GPUs
 
 public:
     explicit Prover(zk_prover *h) : h_(h) {}
-    ~Prover() { zk_prover_destroy(h_); }
+    explicit Prover(zk_multi_prover *m) : m_(m) {}
+    ~Prover() {
+        if (h_) zk_prover_destroy(h_);
+        if (m_) zk_multi_prover_destroy(m_);
+    }
     Prover(const Prover &) = delete;
     Prover &operator=(const Prover &) = delete;
 
@@ -40,15 +46,43 @@ public:
     // (32 B LE) replacing the reference's randombytes_buf (src/groth16.cpp:216-217).
     std::unique_ptr<Proof> prove(const void *wtns, const uint8_t *r32 = nullptr, const uint8_t *s32 = nullptr) {
         std::unique_ptr<Proof> p(new Proof());
-        if (zk_prove(h_, static_cast<const uint8_t *>(wtns), r32, s32, &p->raw) != 0) throw std::runtime_error(zk_last_error());
+        const auto *w = static_cast<const uint8_t *>(wtns);
+        const int rc = m_ ? zk_multi_prove(m_, w, r32, s32, &p->raw) : zk_prove(h_, w, r32, s32, &p->raw);
+        if (rc != 0) throw std::runtime_error(zk_last_error());
+        return p;
+    }
+    // Throughput mode (not in the reference, which proves one at a time): up to ZK_MAX_IN_FLIGHT proofs
+    // enqueued; `wtns` must stay valid until the matching collect().
+    void submit(const void *wtns, const uint8_t *r32 = nullptr, const uint8_t *s32 = nullptr) {
+        const auto *w = static_cast<const uint8_t *>(wtns);
+        if ((m_ ? zk_multi_prove_submit(m_, w, r32, s32) : zk_prove_submit(h_, w, r32, s32)) != 0) throw std::runtime_error(zk_last_error());
+    }
+    std::unique_ptr<Proof> collect() {
+        std::unique_ptr<Proof> p(new Proof());
+        if ((m_ ? zk_multi_prove_collect(m_, &p->raw) : zk_prove_collect(h_, &p->raw)) != 0) throw std::runtime_error(zk_last_error());
         return p;
     }
 };
 
+// "0,1,2,3" -> {0,1,2,3}
+inline std::vector<int32_t> parseDeviceList(const char *s) {
+    std::vector<int32_t> v;
+    while (s && *s) {
+        char *end = nullptr;
+        long d = strtol(s, &end, 10);
+        if (end == s) throw std::invalid_argument("ZKHIP_DEVICES must be a comma-separated list of device ordinals");
+        v.push_back((int32_t)d);
+        s = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') throw std::invalid_argument("ZKHIP_DEVICES must be a comma-separated list of device ordinals");
+    }
+    return v;
+}
+
 inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint32_t domainSize, uint64_t nCoefs,
                                           void *vk_alpha1, void *vk_beta1, void *vk_beta2, void *vk_delta1, void *vk_delta2,
                                           void *coefs, void *pointsA, void *pointsB1, void *pointsB2, void *pointsC,
-                                          void *pointsH, const uint64_t sectionBytes[6] = nullptr, bool precompDefault = false) {
+                                          void *pointsH, const uint64_t sectionBytes[6] = nullptr, bool precompDefault = false,
+                                          int device = -1) {
     zk_zkey_view v{};
     v.nVars = nVars;
     v.nPublic = nPublic;
@@ -79,7 +113,20 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     // proofs).  Default: off for the one-shot CLI, on for the server where create is amortised.
     const char *pc = getenv("ZKHIP_PRECOMP");
     if (pc ? (pc[0] == '1') : precompDefault) o.flags |= ZK_FLAG_PRECOMP;
-    if (const char *dev = getenv("ZKHIP_DEVICE")) o.device = atoi(dev);
+    if (device >= 0) o.device = device;
+    else if (const char *dev = getenv("ZKHIP_DEVICE")) o.device = atoi(dev);
+    // ZKHIP_DEVICES=0,1,...,7: ONE proof over several GPUs of the node — every MSM table sharded by point
+    // range, the A.w/B.w rows and the transforms partitioned the same way (zk_multi_prover).  Only when no
+    // explicit device was asked for (the server's per-GPU workers pass one).
+    if (device < 0) {
+        const std::vector<int32_t> devs = parseDeviceList(getenv("ZKHIP_DEVICES"));
+        if (devs.size() > 1) {
+            zk_multi_prover *m = nullptr;
+            if (zk_multi_prover_create(&m, &v, devs.data(), (uint32_t)devs.size(), &o) != 0) throw std::runtime_error(zk_last_error());
+            return std::unique_ptr<Prover>(new Prover(m));
+        }
+        if (devs.size() == 1) o.device = devs[0];
+    }
     zk_prover *h = nullptr;
     if (zk_prover_create(&h, &v, &o) != 0) throw std::runtime_error(zk_last_error());
     return std::unique_ptr<Prover>(new Prover(h));

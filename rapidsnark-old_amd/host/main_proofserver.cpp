@@ -5,6 +5,8 @@
 //   POST /input/:circuit    -> body = circom input JSON; 200 at once, job runs in the background
 //   POST /cancel            -> abort()
 //   POST /start, /stop      -> 200, no-ops (proverapi.cpp:27-33)
+// Throughput mode (ZKHIP_QUEUE=n, see fullprover.hpp): POST /input/:circuit answers {"job":id} (503 when n
+// requests are already waiting) and GET /status/<id> reports that job; everything else is unchanged.
 // One HTTP thread, bodies up to 128000000 bytes (main_proofserver.cpp:32).
 #include <arpa/inet.h>
 #include <cerrno>
@@ -89,12 +91,23 @@ static void handle(int fd, FullProver &fp) {
     body.resize(clen);
 
     if (method == "GET" && target == "/status") return respond(fd, 200, "OK", fp.getStatus(), "application/json");
+    if (method == "GET" && fp.queueMode() && target.rfind("/status/", 0) == 0 && target.size() > 8) {   // throughput mode: one job's document
+        char *end = nullptr;
+        const unsigned long long id = strtoull(target.c_str() + 8, &end, 10);
+        if (*end) return respond(fd, 404, "Not Found", "Could not find a matching route", "text/plain");
+        return respond(fd, 200, "OK", fp.getStatus(id), "application/json");
+    }
     if (method == "POST" && (target == "/start" || target == "/stop")) return respond(fd, 200, "OK", "", nullptr);
     if (method == "POST" && target == "/cancel") {
         fp.abort();
         return respond(fd, 200, "OK", "", nullptr);
     }
     if (method == "POST" && target.rfind("/input/", 0) == 0 && target.size() > 7 && target.find('/', 7) == std::string::npos) {
+        if (fp.queueMode()) {      // ZKHIP_QUEUE=n: requests queue up instead of replacing each other
+            uint64_t id = 0;
+            if (!fp.enqueue(body, target.substr(7), id)) return respond(fd, 503, "Service Unavailable", "{\"error\":\"queue full\"}", "application/json");
+            return respond(fd, 200, "OK", "{\"job\":" + std::to_string(id) + "}", "application/json");
+        }
         fp.startProve(body, target.substr(7));
         return respond(fd, 200, "OK", "", nullptr);
     }

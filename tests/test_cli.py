@@ -80,3 +80,18 @@ def test_parity_kit_self_check_on_our_prover():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refcheck", "refcheck.py"), "--ours"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("IDENTICAL") == 10 and "PINNED" in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0,0,0,0", "0,0,0"])
+def test_cli_over_several_devices(tmp_path, devices):
+    """ZKHIP_DEVICES=...: the reference's own argv, one proof split over several GPUs (zk_multi_prover; here
+    every shard on the box's one GPU).  2/8 shards partition the chain, 3 replicate it; same output bytes."""
+    name = "r1cs_n256"
+    meta = golden_json(name, "meta.json")
+    le = lambda x: int(x).to_bytes(32, "little").hex()
+    r = run(golden_path(name, "circuit.zkey"), golden_path(name, "witness.wtns"), str(tmp_path / "p.json"), str(tmp_path / "q.json"),
+            env={"ZKHIP_DEVICES": devices, "ZKHIP_FIXED_R": le(meta["r"]), "ZKHIP_FIXED_S": le(meta["s"])})
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "p.json").read_bytes() == golden_bytes(name, "proof.json")
+    assert (tmp_path / "q.json").read_bytes() == golden_bytes(name, "public.json")

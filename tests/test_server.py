@@ -115,3 +115,102 @@ def test_rest_flow_matches_golden(tmp_path):
     finally:
         srv.terminate()
         srv.wait(10)
+
+
+def _start_server(tmp_path, names, env_extra):
+    build = tmp_path / "build"
+    build.mkdir(exist_ok=True)
+    zkeys = []
+    for n in names:
+        z = tmp_path / (n + ".zkey")
+        shutil.copy(golden_path(n, "circuit.zkey"), z)
+        zkeys.append(str(z))
+        gen = build / n                                     # stand-in for the circom witness generator: argv as the reference passes it
+        gen.write_text("#!/bin/sh\necho generating $1\nsleep 0.05\ncp %s \"$2\"\n" % golden_path(n, "witness.wtns"))
+        gen.chmod(gen.stat().st_mode | stat.S_IEXEC)
+    port = _free_port()
+    env = dict(os.environ, **env_extra)
+    srv = subprocess.Popen([SERVER, str(port)] + zkeys, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for _ in range(600):
+        try:
+            _http(port, "GET", "/status")
+            return srv, port
+        except (ConnectionError, urllib.error.URLError):
+            assert srv.poll() is None, srv.stderr.read().decode()
+            time.sleep(0.1)
+    raise AssertionError("server did not come up")
+
+
+@pytest.mark.gpu
+def test_throughput_mode_concurrent_requests_all_golden(tmp_path):
+    """BASELINE configs[4] shape: ZKHIP_QUEUE + ZKHIP_WORKERS — many /input requests fired at once, every
+    one of them answered with the golden proof of ITS circuit (fixed r, s), none dropped or replaced.
+    Two worker replicas share the box's one GPU (ZKHIP_WORKERS=0,0): one dispatcher thread per replica,
+    up to three proofs in flight on each, witness generators running beside them."""
+    import concurrent.futures
+    names = ["r1cs_n8", "r1cs_n64", "r1cs_n256"]
+    meta = golden_json("r1cs_n64", "meta.json")            # the fixtures share (r, s)? no: use each fixture's own below
+    metas = {n: golden_json(n, "meta.json") for n in names}
+    assert len({(m["r"], m["s"]) for m in metas.values()}) >= 1
+    # fixed (r, s) come from the environment, one pair per server: run one server per (r, s) group
+    groups = {}
+    for n in names:
+        groups.setdefault((metas[n]["r"], metas[n]["s"]), []).append(n)
+    for (r, s), group in groups.items():
+        sub = tmp_path / ("g%d" % (hash((r, s)) & 0xffff))
+        sub.mkdir()
+        srv, port = _start_server(sub, group, {"ZKHIP_FIXED_R": _le_hex(r), "ZKHIP_FIXED_S": _le_hex(s), "ZKHIP_QUEUE": "64",
+                                               "ZKHIP_WORKERS": "0,0", "ZKHIP_WITNESS_THREADS": "3"})
+        try:
+            assert json.loads(_http(port, "GET", "/status")[1]) == {"status": "ready"}
+            reqs = [group[i % len(group)] for i in range(24)]
+
+            def fire(circuit):
+                st, body, ctype = _http(port, "POST", "/input/" + circuit, b'{"in": 1}')
+                assert st == 200 and ctype == "application/json"
+                return circuit, json.loads(body)["job"]
+
+            with concurrent.futures.ThreadPoolExecutor(8) as ex:
+                issued = list(ex.map(fire, reqs))
+            assert len({j for _, j in issued}) == len(reqs)                    # every request got its own job
+            for circuit, job in issued:
+                for _ in range(3000):
+                    doc = json.loads(_http(port, "GET", "/status/%d" % job)[1])
+                    if doc["status"] != "busy":
+                        break
+                    time.sleep(0.01)
+                assert doc["status"] == "success", doc
+                assert doc["proof"] == golden_bytes(circuit, "proof.json").decode()
+                assert doc["pubData"] == golden_bytes(circuit, "public.json").decode()
+            # failures stay per job; the queue keeps serving
+            bad = json.loads(_http(port, "POST", "/input/" + group[0], b'{"x": ')[1])["job"]
+            unknown = json.loads(_http(port, "POST", "/input/nosuch", b"{}")[1])["job"]
+            good = json.loads(_http(port, "POST", "/input/" + group[0], b"{}")[1])["job"]
+            docs = {}
+            for job in (bad, unknown, good):
+                for _ in range(3000):
+                    docs[job] = json.loads(_http(port, "GET", "/status/%d" % job)[1])
+                    if docs[job]["status"] != "busy":
+                        break
+                    time.sleep(0.01)
+            assert docs[bad]["status"] == "failed" and "JSON" in docs[bad]["error"]
+            assert docs[unknown]["status"] == "failed" and "unknown circuit" in docs[unknown]["error"]
+            assert docs[good]["status"] == "success"
+            assert json.loads(_http(port, "GET", "/status/999999")[1])["status"] == "failed"
+            assert json.loads(_http(port, "GET", "/status")[1])["status"] == "success"     # the most recent job
+            assert srv.poll() is None
+        finally:
+            srv.terminate()
+            srv.wait(10)
+
+
+@pytest.mark.gpu
+def test_queue_full_is_503(tmp_path):
+    srv, port = _start_server(tmp_path, ["r1cs_n8"], {"ZKHIP_QUEUE": "1", "ZKHIP_WITNESS_THREADS": "1"})
+    try:
+        codes = [_http(port, "POST", "/input/r1cs_n8", b"{}")[0] for _ in range(12)]
+        assert codes[0] == 200 and 503 in codes           # one witness thread, 50 ms generator: the one-deep queue overflows
+        assert set(codes) <= {200, 503}
+    finally:
+        srv.terminate()
+        srv.wait(10)
