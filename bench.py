@@ -14,10 +14,13 @@ reported as the extra key `resident_witness` (--witness-in hbm makes it the head
   python bench.py --gpus 1 --steps K --warmup W                      (N = 1)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-N > 1: one process per GPU; every MSM point table is sharded by index range,
-each rank proves its shard (SpMV+NTT are replicated: ~5 % of the work, an all-to-all NTT
-would cost more than it saves), and the only exchange is one RCCL all_gather of the
-384-byte partial-sum record; rank 0 adds the partials and does the O(1) final assembly.
+N > 1: one process per GPU; every MSM point table is sharded by index range and the
+chain (A.w/B.w rows + the six transforms) is PARTITIONED the same way when N is 2, 4 or 8: rank g
+holds block g of a, b, c, h, runs the local stages itself and meets the others in the log2(N) top
+stages through four rounds of RCCL all_to_all per proof (2 x (N-1)/N of a block per transform over
+xGMI; rapidsnark_old_amd.dist.ShardedChain).  The MSM results are exchanged by one all_gather of
+the 384-byte partial-sum record; rank 0 adds the partials and does the O(1) final assembly.
+--chain replicated keeps the round-1 behaviour (every rank runs the whole chain, no all_to_all).
 One proof is split across the ranks => "scaling": "strong".
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel BY TOTAL TIME: the G1 bucket
@@ -61,6 +64,9 @@ def parse():
     ap.add_argument("--witness-in", choices=["host", "hbm"], default="host",
                     help="host (default): witnesses are pageable host arrays and every upload is timed (the reference's contract); "
                          "hbm: witnesses resident in HBM before the timed region")
+    ap.add_argument("--chain", choices=["auto", "partitioned", "replicated"], default="auto",
+                    help="N > 1: partition the A.w/B.w rows and the NTTs across the ranks (auto: when N is 2, 4 or 8) or replicate them")
+    ap.add_argument("--verify", type=int, default=1, help="N > 1: check one sharded proof against an unsharded prover on rank 0 (outside the timed region)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-budget-s", type=float, default=36.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run")
@@ -106,9 +112,30 @@ def main():
     wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes())
     t_gen = time.time() - t0
     t0 = time.time()
+    partitioned = world in (2, 4, 8) and args.chain != "replicated" and k >= 6
+    if args.chain == "partitioned" and not partitioned:
+        raise SystemExit("--chain partitioned needs 2, 4 or 8 ranks")
     prover = ProverFromView(zk, wl, device=local_rank, shard_index=rank, shard_count=world,
-                            window_bits=args.window_bits, timings=True, precomp=bool(args.precomp))
+                            window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned)
     t_create = time.time() - t0
+    chain = None
+    if partitioned:
+        from rapidsnark_old_amd.dist import ShardedChain
+
+        def exchange_via_cpu(dst, src):
+            # single-GPU test hook only (gloo): all_gather of the blocks on the host, then pick this rank's chunks
+            torch.cuda.synchronize()
+            mine = src.cpu()
+            allb = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allb, mine)
+            ch = mine.shape[1] // world
+            out = torch.empty_like(mine)
+            for sidx in range(world):
+                out[:, sidx * ch:(sidx + 1) * ch] = allb[sidx][:, rank * ch:(rank + 1) * ch]
+            dst.copy_(out)
+            torch.cuda.synchronize()
+
+        chain = ShardedChain(prover.lib, prover.h, dist, dev, exchange=exchange_via_cpu if share else None)
 
     # --- distinct witnesses (same on every rank: seeded): pageable host arrays, and HBM copies of
     # the same for the resident-witness leg
@@ -123,7 +150,12 @@ def main():
         r,s (like the reference).  -> (seconds, mean stage timings)."""
         def submit(i):
             j = i % len(wits_host)
-            if in_hbm:
+            if chain is not None:                            # phases + four rounds of all_to_all (RCCL over xGMI)
+                if in_hbm:
+                    chain.submit(d_wtns=wits_dev[j].data_ptr())
+                else:
+                    chain.submit(wtns=wits_host[j])
+            elif in_hbm:
                 prover.submit_dev(wits_dev[j].data_ptr())
             else:
                 prover.submit_host(wits_host[j])             # pageable -> pinned staging -> HBM, all inside the call / its stream
@@ -188,12 +220,24 @@ def main():
     other_elapsed, other_stage = timed_run(not headline_hbm, args.steps, 1)
 
     def one_proof(i):
-        w = wits_dev[i % len(wits_dev)]
-        if world == 1:
-            return prover.prove_dev(w.data_ptr())
-        part = prover.prove_msm_dev(w.data_ptr())
-        parts = zk.gather_partials(part, dist, xdev)
-        return prover.prove_finish(parts) if rank == 0 else None
+        return prover.prove_dev(wits_dev[i % len(wits_dev)].data_ptr())
+
+    # N > 1: one more proof with fixed (r, s), checked on rank 0 against an UNSHARDED prover of the same
+    # key on rank 0's GPU (tables as in the zkey, whole chain on one GPU): the multi-GPU path must
+    # reproduce the single-GPU proof bit for bit.  Outside the timed region.
+    verified = None
+    if world > 1 and args.verify:
+        vr, vs = 0x1234567, 0x7654321
+        if chain is not None:
+            chain.submit(wtns=wits_host[0], r=vr, s=vs)
+        else:
+            prover.submit_host(wits_host[0], vr, vs)
+        parts = zk.gather_partials(prover.collect_msm(), dist, xdev)
+        if rank == 0:
+            sharded = prover.prove_finish(parts, vr, vs)
+            ref = ProverFromView(zk, wl, device=local_rank, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=False)
+            verified = ref.prove_host(wits_host[0], vr, vs) == sharded
+            ref.lib.zk_prover_destroy(ref.h)
 
     latency_ms = latency_host_ms = None
     if world == 1:                        # outside the timed region: strictly one proof at a time
@@ -221,7 +265,7 @@ def main():
     # + 32 B scalar, SURVEY §8d "one G1 MSM = 96*n").  `also`: the longest single launch, the G2
     # accumulation of MSM B2 (160 B per point).
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
-              "log2n": k, "parallelism": "msm-point-shard x%d" % world, "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
+              "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
               "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or (2 if headline_hbm else 3)) if pipelined else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
@@ -255,6 +299,8 @@ def main():
     other = {"value": round(args.steps / other_elapsed, 4), "unit": "proofs/s", "ms_per_step": round(other_elapsed / args.steps * 1e3, 3),
              "steps": args.steps, "note": "same K proofs, timed the same way, outside the headline's timed region"}
     out["host_witness" if headline_hbm else "resident_witness"] = other
+    if verified is not None:
+        out["multi_gpu_proof_equals_single_gpu_proof"] = verified
     if latency_ms is not None:
         out["latency_ms_one_at_a_time"] = {"witness_in_hbm": round(latency_ms, 3), "witness_in_host_memory": round(latency_host_ms, 3)}
     if world == 1 and not args.no_cpu:
@@ -372,7 +418,9 @@ class ProverFromView:
     def prove_finish(self, parts, r=None, s=None):
         arr = (self.L.zk_msm_sums * len(parts))(*[self.L.zk_msm_sums.from_buffer_copy(p) for p in parts])
         out = self.L.zk_proof()
-        self.L.check(self.lib.zk_prove_finish(self.h, arr, len(parts), None, None, self.C.byref(out)))
+        ra, sa = self._k32(r), self._k32(s)
+        self.L.check(self.lib.zk_prove_finish(self.h, arr, len(parts), ra.ctypes.data if ra is not None else None,
+                                              sa.ctypes.data if sa is not None else None, self.C.byref(out)))
         return bytes(out)
 
     def timings(self):

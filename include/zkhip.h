@@ -164,8 +164,8 @@ int zk_multi_prover_info(zk_multi_prover *mp, uint32_t *n_shards, uint32_t *chai
  *         zk_shard_step(ZK_STEP_LOCAL)         local stages + coset shift -> all_to_all(xb <- abc) x3
  *         zk_shard_step(ZK_STEP_CROSS_FORWARD) top stages, in place in xb -> all_to_all(abc <- xb) x3
  *         zk_shard_step(ZK_STEP_FINISH)        h, MSM H, MSM C, joins     -> zk_prove_msm_collect + zk_prove_finish
- *     `stream` (hipStream_t, may be NULL) is the stream the caller's collectives are ordered on: every call
- *     first waits for what is enqueued on it and makes it wait for what the call enqueued. */
+ *     `stream` (hipStream_t; NULL = the default stream) is the stream the caller's collectives are ordered
+ *     on: every call first waits for what is enqueued on it and makes it wait for what the call enqueued. */
 enum { ZK_STEP_CROSS_INVERSE = 1, ZK_STEP_LOCAL = 2, ZK_STEP_CROSS_FORWARD = 3, ZK_STEP_FINISH = 4 };
 int zk_shard_info(zk_prover *p, uint64_t *block_elems, uint32_t *chain_partitioned);
 int zk_shard_set_exchange(zk_prover *p, void *d_abc, void *d_xb);
@@ -192,6 +192,11 @@ int zk_prover_timings(zk_prover *p, double *ms, uint32_t n);
 int zk_fr_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n);
 /* same over Fq — E.f1.mul */
 int zk_fq_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n);
+/* a = A.w, b = B.w: the coefficient accumulation of src/groth16.cpp:62-85 as an operator.  coefs = zkey
+ * section 4 INCLUDING its leading u32 count (packed 44-byte records, src/groth16.hpp:27-35); wtns standard
+ * form; a, b (domainSize x 32 B each) come back in the reference's Montgomery form. */
+int zk_fr_coef_accumulate(uint8_t *a, uint8_t *b, const void *coefs, uint64_t nCoefs, uint32_t domainSize,
+                          const uint8_t *wtns, uint32_t nVars);
 /* In-place natural-order NTT over Fr, Montgomery in/out: inverse=0 -> FFT::fft, 1 -> FFT::ifft
  * (incl. 1/n) (src/groth16.cpp:102,115).  n must be a power of two <= 2^28. */
 int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse);

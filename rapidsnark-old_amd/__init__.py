@@ -9,7 +9,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP cal
 from .binfile import BinFile, open_existing            # noqa: F401
 from .zkey import ZkeyHeader, load_zkey_header          # noqa: F401
 from .wtns import WtnsHeader, load_wtns_header          # noqa: F401
-from .lib import (ZkHipError, load_library, library_path, fr_mul_vec, fq_mul_vec, fr_ntt,   # noqa: F401
+from .lib import (ZkHipError, load_library, library_path, fr_mul_vec, fq_mul_vec, fr_ntt, fr_coef_accumulate,   # noqa: F401
                   fr_abc_to_h, msm_g1, msm_g2, proof_to_json, public_to_json, device_count,
                   synth_chain_g1, synth_chain_g2, fixed_base_g1, fixed_base_g2, g1_mul, g2_mul, assemble, PinnedBuffer)
 from .prover import Prover, MultiProver, prove_files                 # noqa: F401

@@ -969,13 +969,13 @@ int zk_prover_timings(zk_prover *p, double *ms, uint32_t n) {
 namespace {
 
 // stream 1 of the prover <-> the caller's stream (on which its collectives are ordered)
+// (a NULL handle is the default stream, which is what torch.cuda.current_stream() is unless the caller
+// switched streams: it must be ordered like any other)
 void ext_in(zk_prover *p, void *stream) {
-    if (!stream) return;
     HIP_TRY(hipEventRecord(p->ev_ext_in, (hipStream_t)stream));
     HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_ext_in, 0));
 }
 void ext_out(zk_prover *p, void *stream) {
-    if (!stream) return;
     HIP_TRY(hipEventRecord(p->ev_ext_out, p->stream));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->ev_ext_out, 0));
 }
@@ -1279,6 +1279,41 @@ int zk_fr_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n) 
 }
 int zk_fq_mul_vec(uint8_t *out, const uint8_t *a, const uint8_t *b, uint64_t n) {
     return guarded([&] { mul_vec<Fq>(out, a, b, n, launch_fq_mul_vec); });
+}
+
+// a = A.w, b = B.w over the packed coefficient records — the accumulation loop of src/groth16.cpp:62-85
+// as an operator: same records (section 4 incl. its u32 count), same witness form, a and b come back
+// in the reference's Montgomery form (what its a[] / b[] arrays hold after line 85).
+int zk_fr_coef_accumulate(uint8_t *a, uint8_t *b, const void *coefs, uint64_t nCoefs, uint32_t domainSize, const uint8_t *wtns, uint32_t nVars) {
+    return guarded([&] {
+        need_device();
+        if (!a || !b || !coefs || !wtns || !domainSize || !nVars) throw std::invalid_argument("null argument");
+        if (nCoefs >= (1ull << 32)) throw std::invalid_argument("nCoefs >= 2^32 is not supported");
+        const uint32_t rows = 2 * domainSize;
+        DevBuf<uint8_t> raw;
+        DevBuf<uint32_t> cursor, err, rowptr, col;
+        DevBuf<Fr> val, w, ab;
+        raw.alloc(nCoefs ? nCoefs * 44 : 4);
+        cursor.alloc(rows);
+        err.alloc(1);
+        rowptr.alloc((size_t)rows + 1 + msm_scan_extra_words(rows));
+        col.alloc(nCoefs ? nCoefs : 1);
+        val.alloc(nCoefs ? nCoefs : 1);
+        w.alloc(nVars);
+        ab.alloc(3 * (size_t)domainSize);
+        if (nCoefs) HIP_TRY(hipMemcpy(raw.p, (const uint8_t *)coefs + 4, nCoefs * 44, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.p, wtns, (size_t)nVars * 32, hipMemcpyHostToDevice));
+        launch_csr_build(rowptr.p, col.p, val.p, cursor.p, err.p, raw.p, nCoefs, domainSize, nVars, 0, domainSize, 0);
+        launch_fr_to_internal(val.p, nCoefs, 2, 0);
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpy(&bad, err.p, 4, hipMemcpyDeviceToHost));
+        if (bad) throw std::invalid_argument("zkey coefficient record out of range");
+        CsrDev csr{rowptr.p, col.p, val.p};
+        launch_spmv_abc(ab.p, ab.p + domainSize, ab.p + 2 * (size_t)domainSize, csr, w.p, domainSize, 0);
+        launch_fr_from_internal(ab.p, 2 * (size_t)domainSize, 0);
+        HIP_TRY(hipMemcpy(a, ab.p, (size_t)domainSize * 32, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b, ab.p + domainSize, (size_t)domainSize * 32, hipMemcpyDeviceToHost));
+    });
 }
 
 int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse) {

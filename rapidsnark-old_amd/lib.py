@@ -50,7 +50,7 @@ ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "ms
 # every symbol include/zkhip.h declares (tests check the library exports all of them)
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
            "zk_prove_dev_submit", "zk_prove_submit", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
-           "zk_fq_mul_vec", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
+           "zk_fq_mul_vec", "zk_fr_coef_accumulate", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
            "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble",
            "zk_multi_prover_create", "zk_multi_prover_destroy", "zk_multi_prove", "zk_multi_prove_submit", "zk_multi_prove_collect",
            "zk_multi_prover_info", "zk_shard_info", "zk_shard_set_exchange", "zk_shard_begin", "zk_shard_step"]
@@ -107,6 +107,7 @@ def load_library():
     lib.zk_shard_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     for name in ("zk_fr_mul_vec", "zk_fq_mul_vec"):
         getattr(lib, name).argtypes = [u8p, u8p, u8p, C.c_uint64]
+    lib.zk_fr_coef_accumulate.argtypes = [u8p, u8p, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32]
     lib.zk_fr_ntt.argtypes = [u8p, C.c_uint64, C.c_int]
     lib.zk_fr_abc_to_h.argtypes = [u8p, u8p, u8p, C.c_uint64]
     lib.zk_msm_g1.argtypes = [u8p, u8p, u8p, C.c_uint64]
@@ -181,6 +182,16 @@ def fr_mul_vec(a, b):
 
 def fq_mul_vec(a, b):
     return _mul_vec(load_library().zk_fq_mul_vec, a, b)
+
+
+def fr_coef_accumulate(coefs, n_coefs, domain_size, wtns):
+    """(a, b) = (A.w, B.w) from the packed coefficient records (zkey section 4 image incl. its u32 count) —
+    src/groth16.cpp:62-85; a, b as numpy uint8 arrays, Montgomery form."""
+    coefs, wtns = _buf(coefs), _buf(wtns)
+    a = np.empty(domain_size * 32, dtype=np.uint8)
+    b = np.empty(domain_size * 32, dtype=np.uint8)
+    check(load_library().zk_fr_coef_accumulate(_ptr(a), _ptr(b), _ptr(coefs), n_coefs, domain_size, _ptr(wtns), wtns.size // 32))
+    return a, b
 
 
 def fr_ntt(data, inverse=False):
