@@ -167,14 +167,7 @@ def expected_proof_dlogs(key, r, s):
     t = key["trap"]
     tau, alpha, beta, gamma, delta = t["toxic"]
     w, npub, nv = key["witness"], key["nPublic"], key["nVars"]
-    r1 = _const(MONT, nv)
-
-    def dot(vec, lo=0):                       # sum vec_i * w_i over i >= lo
-        prod = _mul(_mul(vec, w), r1)         # (v w / R) R / R ... = v*w standard: (v*w/R)*(R^2... see below
-        return _sum_mod(prod.reshape(-1, 32)[lo:])
-
-    # _mul(v, w) = v w / R ; times R^2/R = v w : use R^2
-    def dot_exact(vec, lo=0):
+    def dot_exact(vec, lo=0):          # sum vec_i * w_i over i >= lo: (v w / R) * R^2 / R = v w, summed exactly, then mod r
         prod = _mul(_mul(vec, w), _const(MONT * MONT, nv))
         return _sum_mod(prod.reshape(-1, 32)[lo:])
 

@@ -104,8 +104,7 @@ def test_shard_step_api_with_emulated_all_to_all(zk, shards):
     for i, p in enumerate(provers):
         chains.append(ShardedChain(p._lib, p._h, None, torch.device("cuda:0"), exchange=make_exchange(i)))
 
-    def run_all_to_all():
-        torch.cuda.synchronize()
+    def run_all_to_all():          # stream-ordered copies on torch's current (default) stream: no host synchronisation
         reqs = sorted(pending, key=lambda t: t[0])
         assert [t[0] for t in reqs] == list(range(shards))
         srcs = [t[2].clone() for t in reqs]
@@ -114,7 +113,6 @@ def test_shard_step_api_with_emulated_all_to_all(zk, shards):
                 ch = dst.shape[1] // shards
                 for sidx in range(shards):
                     dst[poly, sidx * ch:(sidx + 1) * ch] = srcs[sidx][poly, rnk * ch:(rnk + 1) * ch]
-        torch.cuda.synchronize()
         pending.clear()
 
     # drive the ranks in lock-step: each phase of every rank, then the exchange

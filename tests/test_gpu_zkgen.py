@@ -1,0 +1,82 @@
+"""rapidsnark_old_amd.zkgen — the product-side generator of trapdoor-VALID keys: every proof
+of such a key must be (a G1, b G2, c G1) with a, b, c computed from the toxic waste in Fr alone
+(pairing-free check of SURVEY §8c item 2).  Checked through the C-ABI, the C restatement and the CLI."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import bn254 as bn, c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+G1B = bn.g1_to_bytes(bn.G1.gen)
+G2B = bn.g2_to_bytes(bn.G2.gen)
+
+
+def test_coef_accumulate_operator_matches_oracle(zk):
+    """zk_fr_coef_accumulate = the loop of src/groth16.cpp:62-85: against big-int arithmetic on a synthetic record set."""
+    from rapidsnark_old_amd import synth
+    k = 8
+    n = 1 << k
+    img = synth.make_coefs(k, 1, 0)
+    w = synth.make_witness(k)
+    a, b = zk.fr_coef_accumulate(img, (img.size - 4) // 44, n, w)
+    rec = np.frombuffer(img[4:].tobytes(), dtype=synth.COEF_DTYPE)
+    wi = [int.from_bytes(w[32 * i:32 * i + 32].tobytes(), "little") for i in range(n)]
+    want = [[0] * n, [0] * n]
+    for r_ in rec:
+        v = int.from_bytes(r_["v"].tobytes(), "little")
+        want[int(r_["m"])][int(r_["c"])] = (want[int(r_["m"])][int(r_["c"])] + bn.mont_mul(wi[int(r_["s"])], v, bn.R_MOD)) % bn.R_MOD
+    got_a = [int.from_bytes(a[32 * i:32 * i + 32].tobytes(), "little") for i in range(n)]
+    got_b = [int.from_bytes(b[32 * i:32 * i + 32].tobytes(), "little") for i in range(n)]
+    assert got_a == want[0] and got_b == want[1]
+
+
+@pytest.mark.parametrize("k,npub", [(6, 1), (12, 2), (16, 3)])
+def test_generated_key_is_valid(zk, k, npub):
+    from rapidsnark_old_amd import zkgen
+    import bench
+    key = zkgen.generate(k, npub, seed=7)
+    assert key["nVars"] == 1 << k and key["pointsC"].size == (key["nVars"] - npub - 1) * 64
+    r, s = 0x13579BDF, (1 << 247) - 99
+    a, b, c = zkgen.expected_proof_dlogs(key, r, s)
+    want = zk.g1_mul(G1B, a) + zk.g2_mul(G2B, b) + zk.g1_mul(G1B, c)
+    for precomp in (False, True):
+        p = bench.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=precomp)
+        assert p.prove_host(key["witness"], r, s) == want
+        p.lib.zk_prover_destroy(p.h)
+    # the independent CPU restatement proves the same key to the same bytes
+    assert co.prove(co.ZkeyView(key), key["witness"], r, s) == want
+    # a witness that does not satisfy the circuit does NOT pass the trapdoor identity
+    bad = key["witness"].copy()
+    bad[32 * (key["nVars"] - 1)] ^= 1
+    p = bench.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False)
+    assert p.prove_host(bad, r, s) != want
+    p.lib.zk_prover_destroy(p.h)
+    vk = zkgen.verification_key(key)
+    assert vk["nPublic"] == npub and len(vk["IC"]) == npub + 1 and vk["vk_alpha_1"][2] == "1"
+    tau, alpha, beta, gamma, delta = key["trap"]["toxic"]
+    assert [int(x) for x in vk["vk_alpha_1"][:2]] == list(bn.G1.mul(bn.G1.gen, alpha))
+    g2 = bn.G2.mul(bn.G2.gen, gamma)
+    assert [[int(x) for x in pair] for pair in vk["vk_gamma_2"][:2]] == [list(g2[0]), list(g2[1])]
+
+
+def test_zkgen_tool_at_2p20_with_cli(zk, tmp_path):
+    """tools/zkgen.py 20 --prove: a valid key at BASELINE configs[1]'s size written to disk (~1.1 GB .zkey), proved by
+    the one-shot CLI, proof.json checked against the toxic waste; the multi-GPU path proves the same file."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "zkgen.py"), "20", str(tmp_path), "--prove"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "trapdoor check of proof.json: PASS" in res.stdout, res.stdout + res.stderr
+    vk = json.load(open(tmp_path / "verification_key.json"))
+    assert vk["protocol"] == "groth16" and vk["curve"] == "bn128" and len(vk["IC"]) == 3
+    pub = json.load(open(tmp_path / "public.json"))
+    assert len(pub) == 2
+    r, s = 0x0123456789ABCDEF, (1 << 200) + 12345
+    mp = zk.MultiProver(str(tmp_path / "circuit.zkey"), [0, 0, 0, 0], precomp=True)
+    proof = mp.prove(str(tmp_path / "witness.wtns"), r, s)
+    mp.close()
+    assert zk.proof_to_json(proof) == open(tmp_path / "proof.json").read()
