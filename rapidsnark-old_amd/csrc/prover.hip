@@ -63,6 +63,60 @@ struct DevBuf {
     }
 };
 
+// Host image -> HBM for the big zkey sections (src/binfile_utils.cpp:28-33 copies the whole file into a
+// malloc'ed image first; here the image is the caller's, normally a read-only mmap of the .zkey: pageable
+// and possibly not yet in the page cache).  Two pinned staging chunks: while chunk k's DMA runs, four host
+// threads pull chunk k+1 out of the mapping (page faults / disk reads happen there, off the DMA's path).
+// A source that is already page-locked is copied from directly.
+struct StreamUploader {
+    static constexpr size_t CHUNK = (size_t)64 << 20;
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t s;
+    int k = 0;
+    explicit StreamUploader(hipStream_t s_) : s(s_) {}
+    ~StreamUploader() {
+        for (int i = 0; i < 2; i++) {
+            if (done[i]) {
+                (void)hipEventSynchronize(done[i]);
+                (void)hipEventDestroy(done[i]);
+            }
+            if (pin[i]) (void)hipHostFree(pin[i]);
+        }
+    }
+    void copy(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return;
+        hipPointerAttribute_t attr;
+        const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (pinned || bytes < ((size_t)4 << 20)) {
+            HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+            return;
+        }
+        for (size_t off = 0; off < bytes; off += CHUNK, k ^= 1) {
+            const size_t len = bytes - off < CHUNK ? bytes - off : CHUNK;
+            if (!pin[k]) {
+                HIP_TRY(hipHostMalloc((void **)&pin[k], CHUNK, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+            } else {
+                HIP_TRY(hipEventSynchronize(done[k]));          // the DMA that last read this chunk
+            }
+            const uint8_t *from = (const uint8_t *)src + off;
+            uint8_t *to = pin[k];
+            const size_t nt = 4, per = (len / nt + 4095) & ~(size_t)4095;
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; t++) {
+                const size_t lo = t * per, hi = lo + per < len ? lo + per : len;
+                if (lo < hi) th.emplace_back([=] { memcpy(to + lo, from + lo, hi - lo); });
+            }
+            memcpy(to, from, per < len ? per : len);
+            for (auto &t : th) t.join();
+            HIP_TRY(hipMemcpyAsync((uint8_t *)dst + off, to, len, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipEventRecord(done[k], s));
+        }
+    }
+};
+
 struct Slice {
     uint64_t lo, hi;
     uint64_t size() const { return hi - lo; }
@@ -388,6 +442,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->wbits = wbits;
     hipStream_t s = p->stream;
     clk.lap("device + streams", s);
+    StreamUploader up(s);
 
     // --- this shard's contiguous slices of the witness indices and of the domain
     p->sv = shard_slice(nV, p->shard_index, p->shard_count);
@@ -418,7 +473,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->csr_rowptr.alloc((size_t)rows + 1 + msm_scan_extra_words(rows));
         p->csr_col.alloc(nnz ? nnz : 1);
         p->csr_val.alloc(nnz ? nnz : 1);
-        if (nnz) HIP_TRY(hipMemcpyAsync(raw.p, (const uint8_t *)z->coefs + 4, nnz * 44, hipMemcpyHostToDevice, s));
+        if (nnz) up.copy(raw.p, (const uint8_t *)z->coefs + 4, nnz * 44);
         clk.lap("coefficient records upload", s);
         launch_csr_build(p->csr_rowptr.p, p->csr_col.p, p->csr_val.p, cursor.p, err.p, raw.p, nnz, z->domainSize, z->nVars,
                          p->part ? (uint32_t)p->sh.lo : 0u, p->part ? (uint32_t)p->sh.hi : z->domainSize, s);
@@ -450,10 +505,10 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->ptsB2.alloc((nv ? nv : 1) * rows_w);
     p->ptsH.alloc((nh ? nh : 1) * rows_h);
     clk.lap("workspace allocation", s);
-    p->ptsA.upload((const uint8_t *)z->pointsA + p->sv.lo * 64, nv, s);
-    p->ptsB1.upload((const uint8_t *)z->pointsB1 + p->sv.lo * 64, nv, s);
-    p->ptsB2.upload((const uint8_t *)z->pointsB2 + p->sv.lo * 128, nv, s);
-    p->ptsH.upload((const uint8_t *)z->pointsH + p->sh.lo * 64, nh, s);
+    up.copy(p->ptsA.p, (const uint8_t *)z->pointsA + p->sv.lo * 64, nv * 64);
+    up.copy(p->ptsB1.p, (const uint8_t *)z->pointsB1 + p->sv.lo * 64, nv * 64);
+    up.copy(p->ptsB2.p, (const uint8_t *)z->pointsB2 + p->sv.lo * 128, nv * 128);
+    up.copy(p->ptsH.p, (const uint8_t *)z->pointsH + p->sh.lo * 64, nh * 64);
     // C: witness index i (global) uses pointsC[i - nPublic - 1] for i > nPublic (src/groth16.cpp:204)
     {
         uint64_t first = z->nPublic + 1;                 // first global witness index with a C point
@@ -465,13 +520,13 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             // same row indexing as A/B1 (entries address row j*nv + i): pad the public rows with infinity
             p->ptsC.alloc((nv ? nv : 1) * rows_w);
             HIP_TRY(hipMemsetAsync(p->ptsC.p, 0, (size_t)(nv ? nv : 1) * 64, s));
-            if (cnt) HIP_TRY(hipMemcpyAsync(p->ptsC.p + skip, (const uint8_t *)z->pointsC + (lo - first) * 64, cnt * 64, hipMemcpyHostToDevice, s));
+            if (cnt) up.copy(p->ptsC.p + skip, (const uint8_t *)z->pointsC + (lo - first) * 64, cnt * 64);
             p->c_idx_min = 0;
             launch_fq_to_internal((Fq *)p->ptsC.p, nv * 2, s);
         } else {
             p->c_idx_min = skip;
             p->ptsC.alloc(cnt ? cnt : 1);
-            p->ptsC.upload((const uint8_t *)z->pointsC + (lo - first) * 64, cnt, s);
+            up.copy(p->ptsC.p, (const uint8_t *)z->pointsC + (lo - first) * 64, cnt * 64);
             launch_fq_to_internal((Fq *)p->ptsC.p, cnt * 2, s);
         }
     }

@@ -37,8 +37,18 @@ def main():
     binfile(wpath, b"wtns", 2, [(1, struct.pack("<I", 32) + R_MOD.to_bytes(32, "little") + struct.pack("<I", wl["nVars"])), (2, np.asarray(w).tobytes())])
     print("zkey %.1f MB, wtns %.1f MB" % (os.path.getsize(zpath) / 1e6, os.path.getsize(wpath) / 1e6), flush=True)
     exe = os.path.join(ROOT, "rapidsnark-old_amd", "prover")
+    def evict(path):          # drop the file's clean pages from the page cache: the next run reads it from disk ("cold")
+        fd = os.open(path, os.O_RDONLY)
+        os.fsync(fd)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        os.close(fd)
+
     for mode in ("0", "1"):
         for i in range(runs):
+            if i == 0:
+                evict(zpath)
+                evict(wpath)
+            print("=== %s page cache" % ("COLD" if i == 0 else "warm"))
             env = dict(os.environ, ZKHIP_VERBOSE="1", ZKHIP_PRECOMP=mode)
             t0 = time.perf_counter()
             out = subprocess.run([exe, zpath, wpath, os.path.join(d, "p.json"), os.path.join(d, "q.json")], capture_output=True, text=True, env=env)
