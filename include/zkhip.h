@@ -180,7 +180,9 @@ int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta
 
 /* Device times of the last prove, ms (needs ZK_FLAG_TIMINGS), from hipEvents on the library's own
  * streams.  Two streams overlap (h chain | witness MSMs), so stage walls are not additive;
- * the *_L1_KERNEL entries bracket exactly one launch of the level-1 accumulation kernel. */
+ * ZK_T_G1_L1_KERNEL is the mean duration of the four launches of the G1 level-1 accumulation kernel of the
+ * last proof (MSM A, B1, C, H; events immediately before/after each launch, on its stream), ZK_T_G2_L1_KERNEL
+ * the one launch of the G2 kernel, ZK_T_WTNS_H2D the witness upload of a host-witness proof. */
 enum {
     ZK_T_SPMV = 0, ZK_T_NTT, ZK_T_DIGITS_SORT, ZK_T_MSM_H, ZK_T_JOIN_WAIT, ZK_T_MSM_REDUCE,
     ZK_T_TOTAL_DEVICE, ZK_T_G1_L1_KERNEL, ZK_T_G2_L1_KERNEL, ZK_T_WTNS_H2D, ZK_T_COUNT

@@ -458,13 +458,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 //   * a bucket run that starts and ends inside the chunk is complete -> buckets[b];
 //   * a run cut by the chunk's left edge goes to the lane's HEAD slot, one cut by the right
 //     edge to its TAIL slot (at most one of each), tagged with its bucket and STARTS/ENDS flags;
-//   * the slot list (2 per lane, still bucket-sorted) is reduced by the same algorithm with
-//     XYZZ inputs (k_msm_accum_ln), shrinking ~ACC_CHUNK_N/2 per level until one lane is left.
+//   * the slot list (2 per lane, still bucket-sorted) is reduced by wave-parallel segmented scans over
+//     XYZZ partials (k_msm_accum_wave), shrinking 32x (G2: 16x) per level until one wave is left.
 // Work per lane is constant, so the kernel time is flat in the scalar distribution.  The chunk
 // is 128 entries, halved (to 32) for small or sharded MSMs so every SIMD still gets ~3 waves.
 #define ACC_CHUNK_MAX 128u  // affine points per lane, level 1 (halved until >= ~3 waves/SIMD of lanes exist)
 #define ACC_CHUNK_MIN 32u
-#define ACC_CHUNK_N 32u     // slots per lane, levels >= 2
+#define ACC_CHUNK_N 32u     // slots per unit at levels >= 2 used to SIZE the workspace (a G2 wave takes 32, a G1 wave 64)
 #define SLOT_EMPTY 0xffffffffu
 #define FLAG_STARTS 1u
 #define FLAG_ENDS 2u
@@ -656,54 +656,98 @@ __global__ __launch_bounds__(256) void k_msm_accum_pair(XYZZ<F> *buckets, const 
     }
 }
 
-// Levels >= 2: the same chunked segmented sum over a bucket-sorted slot list of XYZZ partials.
+// Levels >= 2, wave-parallel: a WAVE takes 64 consecutive slots (32 for G2: a lane pair per element),
+// compacts the non-empty ones to its low lanes (ds_permute), and runs a segmented inclusive scan by
+// bucket key — log2(64) steps of one general add per lane instead of up to ACC_CHUNK_N sequential adds
+// in one lane.  What made the sequential version slow is exactly the data that reaches these levels: a
+// bucket spread over thousands of level-1 chunks (the top window of uniform scalars has ~12 non-empty
+// buckets of n/12 points each; bucket "1" of real witnesses) is a run of thousands of partials, i.e.
+// serial chains of 32 general adds per level (measured 1.3-1.7 ms per level at 2^22, exposed after the
+// last MSM of a proof).  A wave that finds all its slots empty (the common case after the pairwise
+// merge) leaves at once; the scan stops at the first distance no lane has a partner at.  Every wave
+// emits at most two partials (its first run if that does not START there, its last run if it does not
+// END there), so a level shrinks the list 32x (16x for G2).
+template <class R> __device__ __forceinline__ R wave_up(const R &v, uint32_t d);
+template <> __device__ __forceinline__ Fq29 wave_up<Fq29>(const Fq29 &v, uint32_t d) {
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = __shfl_up(v.l[i], d);
+    return r;
+}
+template <> __device__ __forceinline__ Fq2s wave_up<Fq2s>(const Fq2s &v, uint32_t d) { return Fq2s{wave_up<Fq29>(v.v, d)}; }
+template <class R> __device__ __forceinline__ R wave_push(const R &v, uint32_t dst_lane);       // lane L's value -> lane dst_lane (a permutation)
+template <> __device__ __forceinline__ Fq29 wave_push<Fq29>(const Fq29 &v, uint32_t dst) {
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = __builtin_amdgcn_ds_permute((int)(dst << 2), v.l[i]);
+    return r;
+}
+template <> __device__ __forceinline__ Fq2s wave_push<Fq2s>(const Fq2s &v, uint32_t dst) { return Fq2s{wave_push<Fq29>(v.v, dst)}; }
+
 template <class F>
-__global__ __launch_bounds__(128) void k_msm_accum_ln(XYZZ<F> *buckets, const XYZZ<F> *in_part, const uint32_t *in_key,
-                                                      const uint32_t *in_flag, uint32_t nitems, XYZZ<F> *out_part,
-                                                      uint32_t *out_key, uint32_t *out_flag, uint32_t nlanes) {
+__global__ __launch_bounds__(256) void k_msm_accum_wave(XYZZ<F> *buckets, const XYZZ<F> *in_part, const uint32_t *in_key,
+                                                        const uint32_t *in_flag, uint32_t nitems, XYZZ<F> *out_part,
+                                                        uint32_t *out_key, uint32_t *out_flag, uint32_t nwaves) {
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t t = gt / LM::LPE;
-    if (t >= nlanes) return;
-    const uint32_t lo = t * ACC_CHUNK_N;
-    const uint32_t hi = lo + ACC_CHUNK_N < nitems ? lo + ACC_CHUNK_N : nitems;
-    uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
-    uint32_t cur = SLOT_EMPTY, cflag = 0;
-    XYZZ<FR> acc = XYZZ<FR>::inf();
-    auto flush = [&]() {
-        if (cur == SLOT_EMPTY) return;
-        if ((cflag & FLAG_STARTS) && (cflag & FLAG_ENDS)) {
-            LM::store(buckets + cur, acc);
-        } else if (!(cflag & FLAG_STARTS)) {         // continues a bucket begun in an earlier lane
-            LM::store(out_part + 2 * (uint64_t)t, acc);
-            hkey = cur;
-            hflag = cflag & FLAG_ENDS;
-        } else {                                     // starts here, continues in a later lane
-            LM::store(out_part + 2 * (uint64_t)t + 1, acc);
-            tkey = cur;
-            tflag = FLAG_STARTS;
-        }
-    };
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t k = in_key[i];
-        if (k == SLOT_EMPTY) continue;
-        uint32_t fl = in_flag[i];
-        if (k != cur) {
-            flush();
-            cur = k;
-            cflag = fl & FLAG_STARTS;
-            acc = XYZZ<FR>::inf();
-        }
-        cflag = (cflag & FLAG_STARTS) | (fl & FLAG_ENDS);
-        add(acc, LM::load(in_part + i));
+    constexpr uint32_t LPE = LM::LPE, EPW = 64u / LPE;          // lanes per element, elements per wave
+    const uint32_t lane = threadIdx.x & 63u, w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= nwaves) return;                                    // wave-uniform
+    const uint32_t e = lane / LPE, comp = lane % LPE;           // this lane's element slot, component
+    const uint32_t i = w * EPW + e;
+    uint32_t key = i < nitems ? in_key[i] : SLOT_EMPTY;
+    uint32_t flag = key != SLOT_EMPTY ? in_flag[i] : 0u;
+    if (lane == 0) {                                            // ordered before the partial stores below (same wave)
+        out_key[2 * (uint64_t)w] = SLOT_EMPTY;
+        out_key[2 * (uint64_t)w + 1] = SLOT_EMPTY;
+        out_flag[2 * (uint64_t)w] = 0;
+        out_flag[2 * (uint64_t)w + 1] = 0;
     }
-    flush();
-    if (gt % LM::LPE == 0) {
-        out_key[2 * (uint64_t)t] = hkey;
-        out_flag[2 * (uint64_t)t] = hflag;
-        out_key[2 * (uint64_t)t + 1] = tkey;
-        out_flag[2 * (uint64_t)t + 1] = tflag;
+    const uint64_t vmask = __ballot(key != SLOT_EMPTY);
+    if (vmask == 0) return;
+    XYZZ<FR> v = XYZZ<FR>::inf();
+    if (key != SLOT_EMPTY) v = LM::load(in_part + i);
+    // compaction: valid element with `rank` valid elements before it -> element slot rank; the invalid ones fill the rest
+    const uint64_t below = vmask & ((1ull << (e * LPE)) - 1ull);
+    const uint32_t rank = (uint32_t)__popcll(below) / LPE, cnt = (uint32_t)__popcll(vmask) / LPE;
+    const uint32_t dst_e = key != SLOT_EMPTY ? rank : cnt + (e - rank);
+    const uint32_t dst = dst_e * LPE + comp;
+    key = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)key);
+    flag = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)flag);
+    v.x = wave_push(v.x, dst); v.y = wave_push(v.y, dst); v.zz = wave_push(v.zz, dst); v.zzz = wave_push(v.zzz, dst);
+    // segmented inclusive scan over the equal-key runs of elements 0 .. cnt-1
+    for (uint32_t d = 1; d < EPW; d <<= 1) {
+        const uint32_t kprev = __shfl_up(key, d * LPE);
+        const bool take = e >= d && e < cnt && kprev == key;
+        if (!__any(take)) break;                                // runs are contiguous: nothing at 2d either
+        XYZZ<FR> o{wave_up(v.x, d * LPE), wave_up(v.y, d * LPE), wave_up(v.zz, d * LPE), wave_up(v.zzz, d * LPE)};
+        if (take) add(v, o);
+    }
+    if (e >= cnt) return;
+    const uint32_t knext = __shfl_down(key, LPE);
+    const uint32_t kbefore = __shfl_up(key, LPE);
+    const bool last = e + 1 == cnt || knext != key;
+    const bool first = e == 0 || kbefore != key;
+    // STARTS comes from the first element of the run, ENDS from the last one (this lane when `last`)
+    const uint64_t fmask = __ballot(first);
+    const uint32_t start_lane = 63u - (uint32_t)__clzll(fmask & ((2ull << lane) - 1ull));     // highest run start at or below this lane (same comp parity not needed: flags are replicated)
+    const uint32_t sflag = (uint32_t)__shfl((int)flag, (int)start_lane);
+    if (!last) return;
+    const bool starts = (sflag & FLAG_STARTS) != 0, ends = (flag & FLAG_ENDS) != 0;
+    if (starts && ends) {
+        LM::store(buckets + key, v);
+    } else if (!starts) {
+        LM::store(out_part + 2 * (uint64_t)w, v);
+        if (comp == 0) {
+            out_key[2 * (uint64_t)w] = key;
+            out_flag[2 * (uint64_t)w] = ends ? FLAG_ENDS : 0u;
+        }
+    } else {
+        LM::store(out_part + 2 * (uint64_t)w + 1, v);
+        if (comp == 0) {
+            out_key[2 * (uint64_t)w + 1] = key;
+            out_flag[2 * (uint64_t)w + 1] = FLAG_STARTS;
+        }
     }
 }
 
@@ -973,11 +1017,12 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
         hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256)), dim3(256), 0, s, buckets,
                            (const XYZZ<F> *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
     uint64_t off = 0;
-    while (lanes > 1) {          // a single lane has no cut runs: everything it saw was complete
+    while (lanes > 1) {          // a single unit has no cut runs: everything it saw was complete
         uint64_t items = 2 * lanes;
-        uint64_t nl = (items + ACC_CHUNK_N - 1) / ACC_CHUNK_N;
         uint64_t noff = off + items;
-        hipLaunchKernelGGL(k_msm_accum_ln<F>, dim3((uint32_t)((nl * LaneModel<F>::LPE + 127) / 128)), dim3(128), 0, s, buckets, ws_part + off,
+        const uint64_t epw = 64u / LaneModel<F>::LPE;
+        const uint64_t nl = (items + epw - 1) / epw;             // waves; each emits two slots
+        hipLaunchKernelGGL(k_msm_accum_wave<F>, dim3((uint32_t)((nl + 3) / 4)), dim3(256), 0, s, buckets, ws_part + off,
                            ws_key + off, ws_flag + off, (uint32_t)items, ws_part + noff, ws_key + noff, ws_flag + noff, (uint32_t)nl);
         off = noff;
         lanes = nl;

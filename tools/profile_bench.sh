@@ -12,7 +12,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py "$@" > $out/bench.json 2> $out/bench.err
-args="--steps 6 --warmup 2 --no-cpu $*"
+args="--steps 6 --warmup 2 --no-cpu"   # 8 + 7 + 6 = 21 proofs per profiled run (tools/instr_budget.py divides by it)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py $args > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python bench.py $args > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python bench.py $args > $out/write.log 2>&1
