@@ -106,6 +106,15 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
 // tmp: (W-1)*n XYZZ, pref: (W-1)*n field elements (scratch).
 void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s);
 void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s);
+// Bucket sums, partial sums and reduction scratch in HBM: the accumulators' own nine 29-bit limbs per
+// coordinate (lazy, not canonical — msm.hip), all-zero = infinity.  G1: x | y | zz | zzz; G2: the four
+// real components, then the four imaginary ones (what a lane of a lane pair loads in one go).
+struct alignas(16) G1Acc {
+    int32_t l[36];
+};
+struct alignas(16) G2Acc {
+    int32_t l[72];
+};
 // buckets[b] = sum of +-points[idx - idx_sub] over the entries of b with idx >= idx_min.
 // max_entries: upper bound of offsets[total_buckets] (= n*W); ws_*: msm_accum_workspace_slots() slots.
 // ev (optional): two events recorded immediately before/after the level-1 kernel.
@@ -116,18 +125,18 @@ struct AccumTail {
     hipStream_t stream = nullptr;
     hipEvent_t l1_done = nullptr;
 };
-void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
+void launch_msm_accum_g1(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         G1XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
+                         G1Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
                          AccumTail tail = AccumTail());
-void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
+void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         G2XYZZ *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
+                         G2Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
                          AccumTail tail = AccumTail());
 // window_sums[m*W + w] = sum_k (k+1) * buckets[m][w][k]  for n_msm bucket arrays laid back to back;
 // scratch: n_msm * W * nbuckets/REDUCE_CHUNK points
-void launch_msm_reduce_g1(G1XYZZ *window_sums, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
-void launch_msm_reduce_g2(G2XYZZ *window_sums, G2XYZZ *scratch, const G2XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
+void launch_msm_reduce_g1(G1XYZZ *window_sums, G1Acc *scratch, const G1Acc *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
+void launch_msm_reduce_g2(G2XYZZ *window_sums, G2Acc *scratch, const G2Acc *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p);
 
 // MSM tables live in HBM as canonical words of x*2^261 (the 29-bit-limb kernels' Montgomery radix);

@@ -141,33 +141,78 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
     ZK_LAUNCH_OK("fq_to_internal");
 }
 
+// Bucket sums, partial sums and reduction scratch live in HBM as the ACCUMULATORS' OWN LIMBS (G1Acc /
+// G2Acc, kernels.hpp): 36 (72) int32, moved as nine 16-byte accesses per lane.  Storing them as canonical
+// 256-bit words cost ~95 instructions per coordinate (exact reduction, conditional +p, limb -> word
+// packing) in the most divergent spot of the level-1 loop — a bucket run ends in ~46 % of a wave's
+// iterations (64 lanes, ~104 entries per bucket), and the other 63 lanes wait — and the same again to
+// unpack at every load.  Lazy values are valid operands everywhere (field29.hpp); infinity stays the
+// all-zero pattern.
+__device__ __forceinline__ void load36(int32_t *dst, const int32_t *src) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint4 t = q[i];
+        dst[4 * i] = (int32_t)t.x; dst[4 * i + 1] = (int32_t)t.y; dst[4 * i + 2] = (int32_t)t.z; dst[4 * i + 3] = (int32_t)t.w;
+    }
+}
+__device__ __forceinline__ void store36(int32_t *dst, const int32_t *src) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4((uint32_t)src[4 * i], (uint32_t)src[4 * i + 1], (uint32_t)src[4 * i + 2], (uint32_t)src[4 * i + 3]);
+}
+__device__ __forceinline__ XYZZ<Fq29> unpack36(const int32_t *w) {
+    XYZZ<Fq29> v;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { v.x.l[i] = w[i]; v.y.l[i] = w[9 + i]; v.zz.l[i] = w[18 + i]; v.zzz.l[i] = w[27 + i]; }
+    return v;
+}
+__device__ __forceinline__ void pack36(int32_t *w, const Fq29 &x, const Fq29 &y, const Fq29 &zz, const Fq29 &zzz) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { w[i] = x.l[i]; w[9 + i] = y.l[i]; w[18 + i] = zz.l[i]; w[27 + i] = zzz.l[i]; }
+}
+
 // Lane model of the merge / reduction kernels: one lane per G1 element; a lane PAIR per G2 element
 // (even lane = real components, odd lane = imaginary components, curve29.hpp Fq2s) — half the
-// registers per lane, twice the lanes, no spills.  Memory layout is the same either way.
+// registers per lane, twice the lanes, no spills.
 template <class F> struct LaneModel;
 template <> struct LaneModel<Fq> {
     static constexpr uint32_t LPE = 1;      // lanes per element
     typedef Fq29 R;
-    __device__ __forceinline__ static XYZZ<R> load(const G1XYZZ *p) { return load_xyzz(p); }
-    __device__ __forceinline__ static void store(G1XYZZ *p, const XYZZ<R> &v) { store_xyzz(p, v); }
+    typedef G1Acc Mem;
+    __device__ __forceinline__ static XYZZ<R> load(const G1Acc *p) {
+        int32_t w[36];
+        load36(w, p->l);
+        return unpack36(w);
+    }
+    __device__ __forceinline__ static void store(G1Acc *p, const XYZZ<R> &v) {
+        int32_t w[36];
+        pack36(w, v.x, v.y, v.zz, v.zzz);
+        store36(p->l, w);
+    }
     __device__ __forceinline__ static void store256(G1XYZZ *p, const XYZZ<R> &v) { store_xyzz_mont256(p, v); }
 };
 template <> struct LaneModel<Fq2> {
     static constexpr uint32_t LPE = 2;
     typedef Fq2s R;
-    __device__ __forceinline__ static XYZZ<R> load(const G2XYZZ *p) {     // memory: x.a x.b y.a y.b zz.a zz.b zzz.a zzz.b
-        const Fq *c = reinterpret_cast<const Fq *>(p) + (threadIdx.x & 1u);
-        return XYZZ<R>{R{Reg<Fq>::load(c)}, R{Reg<Fq>::load(c + 2)}, R{Reg<Fq>::load(c + 4)}, R{Reg<Fq>::load(c + 6)}};
+    typedef G2Acc Mem;
+    __device__ __forceinline__ static XYZZ<R> load(const G2Acc *p) {      // memory: [component][x | y | zz | zzz][limb]
+        int32_t w[36];
+        load36(w, p->l + 36 * (threadIdx.x & 1u));
+        const XYZZ<Fq29> t = unpack36(w);
+        return XYZZ<R>{R{t.x}, R{t.y}, R{t.zz}, R{t.zzz}};
     }
-    __device__ __forceinline__ static void store(G2XYZZ *p, const XYZZ<R> &v) {
-        Fq *c = reinterpret_cast<Fq *>(p) + (threadIdx.x & 1u);
-        Reg<Fq>::store(c, v.x.v); Reg<Fq>::store(c + 2, v.y.v); Reg<Fq>::store(c + 4, v.zz.v); Reg<Fq>::store(c + 6, v.zzz.v);
+    __device__ __forceinline__ static void store(G2Acc *p, const XYZZ<R> &v) {
+        int32_t w[36];
+        pack36(w, v.x.v, v.y.v, v.zz.v, v.zzz.v);
+        store36(p->l + 36 * (threadIdx.x & 1u), w);
     }
-    __device__ __forceinline__ static void store256(G2XYZZ *p, const XYZZ<R> &v) {
+    __device__ __forceinline__ static void store256(G2XYZZ *p, const XYZZ<R> &v) {   // x.a x.b y.a y.b zz.a zz.b zzz.a zzz.b, canonical words
         Fq *c = reinterpret_cast<Fq *>(p) + (threadIdx.x & 1u);
         Reg<Fq>::store256(c, v.x.v); Reg<Fq>::store256(c + 2, v.y.v); Reg<Fq>::store256(c + 4, v.zz.v); Reg<Fq>::store256(c + 6, v.zzz.v);
     }
 };
+#define ACCMEM typename LaneModel<F>::Mem
 
 // ---------------------------------------------------------------- digits + two-level LDS counting sort
 // Signed c-bit digits d in [-2^(c-1), 2^(c-1) - 1] (a window value >= 2^(c-1) becomes negative
@@ -473,10 +518,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 // Forcing 4 G1 waves (128 VGPRs, 20 B scratch) or 2 G2 waves (256 VGPRs, 256 B scratch) was measured
 // slower for the whole proof.
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries,
+__global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                       const Affine<F> *points, uint32_t idx_min, uint32_t idx_sub,
-                                                      uint32_t nbuckets_total, XYZZ<F> *out_part, uint32_t *out_key,
+                                                      uint32_t nbuckets_total, G1Acc *out_part, uint32_t *out_key,
                                                       uint32_t *out_flag, uint32_t nlanes, uint32_t ACC_CHUNK) {
+    static_assert(sizeof(F) == sizeof(Fq), "G1 only: the G2 level-1 kernel is k_msm_accum_l1_g2s");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nlanes) return;
     const uint32_t E = offsets[nbuckets_total];
@@ -522,13 +568,13 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
             if (e == bend || e == hi) {              // the run of bucket b ends here (or is cut)
                 const bool ends = (e == bend);
                 if (!started_before && ends) {
-                    store_xyzz(buckets + b, acc);
+                    LaneModel<Fq>::store(buckets + b, acc);
                 } else if (started_before) {
-                    store_xyzz(out_part + 2 * (uint64_t)t, acc);
+                    LaneModel<Fq>::store(out_part + 2 * (uint64_t)t, acc);
                     hkey = b;
                     hflag = ends ? FLAG_ENDS : 0u;
                 } else {
-                    store_xyzz(out_part + 2 * (uint64_t)t + 1, acc);
+                    LaneModel<Fq>::store(out_part + 2 * (uint64_t)t + 1, acc);
                     tkey = b;
                     tflag = FLAG_STARTS;
                 }
@@ -549,9 +595,9 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(XYZZ<F> *buckets, const ui
 // G2 level 1 with the accumulator split across lane pairs (curve29.hpp, Fq2s): two lanes per chunk,
 // lane parity = Fq2 component.  Both lanes of a pair walk the same entries, so the loop and every
 // branch are uniform inside the pair (the DPP exchanges need both lanes active).
-__global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries,
+__global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                           const G2Affine *points, uint32_t idx_min, uint32_t idx_sub,
-                                                          uint32_t nbuckets_total, G2XYZZ *out_part, uint32_t *out_key,
+                                                          uint32_t nbuckets_total, G2Acc *out_part, uint32_t *out_key,
                                                           uint32_t *out_flag, uint32_t nlanes, uint32_t ACC_CHUNK) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = gt >> 1, comp = gt & 1u;          // chunk, component (blockDim is even: comp == threadIdx.x & 1)
@@ -559,13 +605,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2XYZZ *buckets, const
     const uint32_t E = offsets[nbuckets_total];
     const uint64_t lo64 = (uint64_t)t * ACC_CHUNK;
     uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
-    auto store_comp = [&](G2XYZZ *dst, const XYZZ<Fq2s> &v) {     // memory: x.a x.b y.a y.b zz.a zz.b zzz.a zzz.b
-        Fq *d = reinterpret_cast<Fq *>(dst) + comp;
-        Reg<Fq>::store(d, v.x.v);
-        Reg<Fq>::store(d + 2, v.y.v);
-        Reg<Fq>::store(d + 4, v.zz.v);
-        Reg<Fq>::store(d + 6, v.zzz.v);
-    };
+    auto store_comp = [&](G2Acc *dst, const XYZZ<Fq2s> &v) { LaneModel<Fq2>::store(dst, v); };   // this lane's component (comp == threadIdx.x & 1)
     if (lo64 < E) {
         const uint32_t lo = (uint32_t)lo64;
         const uint32_t hi = (E - lo > ACC_CHUNK) ? lo + ACC_CHUNK : E;
@@ -636,7 +676,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2XYZZ *buckets, const
 // and both slots are retired; what is left for the serial-ish generic levels is only the
 // buckets spanning three or more chunks (top window, skewed witnesses).
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_accum_pair(XYZZ<F> *buckets, const XYZZ<F> *part, uint32_t *key, const uint32_t *flag,
+__global__ __launch_bounds__(256) void k_msm_accum_pair(ACCMEM *buckets, const ACCMEM *part, uint32_t *key, const uint32_t *flag,
                                                         uint32_t nlanes) {
     typedef LaneModel<F> LM;
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,8 +725,8 @@ template <> __device__ __forceinline__ Fq29 wave_push<Fq29>(const Fq29 &v, uint3
 template <> __device__ __forceinline__ Fq2s wave_push<Fq2s>(const Fq2s &v, uint32_t dst) { return Fq2s{wave_push<Fq29>(v.v, dst)}; }
 
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_accum_wave(XYZZ<F> *buckets, const XYZZ<F> *in_part, const uint32_t *in_key,
-                                                        const uint32_t *in_flag, uint32_t nitems, XYZZ<F> *out_part,
+__global__ __launch_bounds__(256) void k_msm_accum_wave(ACCMEM *buckets, const ACCMEM *in_part, const uint32_t *in_key,
+                                                        const uint32_t *in_flag, uint32_t nitems, ACCMEM *out_part,
                                                         uint32_t *out_key, uint32_t *out_flag, uint32_t nwaves) {
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
@@ -754,7 +794,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_wave(XYZZ<F> *buckets, const 
 // Lane per chunk of REDUCE_CHUNK buckets: running sums give A = sum (j+1)*B[lo+j], T = sum B;
 // X = A + lo*T is the chunk's share of sum_k (k+1)*B_k.
 template <class F>
-__global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, const XYZZ<F> *buckets, uint32_t nbuckets,
+__global__ __launch_bounds__(128) void k_msm_reduce_chunks(ACCMEM *scratch, const ACCMEM *buckets, uint32_t nbuckets,
                                                            uint32_t chunk, uint32_t total_chunks) {
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
@@ -762,7 +802,7 @@ __global__ __launch_bounds__(128) void k_msm_reduce_chunks(XYZZ<F> *scratch, con
     if (t >= total_chunks) return;
     const uint32_t chunks_per_window = nbuckets / chunk;
     const uint32_t cw = t % chunks_per_window;          // chunk index inside its window
-    const XYZZ<F> *B = buckets + (uint64_t)t * chunk;   // windows (and MSMs) are laid back to back
+    const ACCMEM *B = buckets + (uint64_t)t * chunk;    // windows (and MSMs) are laid back to back
     XYZZ<FR> run = XYZZ<FR>::inf(), sum = XYZZ<FR>::inf();
     for (int j = (int)chunk - 1; j >= 0; j--) {
         add(run, LM::load(B + j));
@@ -788,13 +828,13 @@ template <class F>
 static constexpr uint32_t tree_in() { return 2u * REDUCE_THREADS / LaneModel<F>::LPE; }    // inputs per workgroup
 #define TREE_IN_MIN REDUCE_THREADS      // the smaller fan-in (G2): sizes the shared scratch formula
 template <class F>
-__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(XYZZ<F> *out, const XYZZ<F> *in, uint32_t count, uint32_t last) {
+__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out, XYZZ<F> *out_final, const ACCMEM *in, uint32_t count, uint32_t last) {
     extern __shared__ uint32_t lds_raw[];
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
     constexpr uint32_t NE = REDUCE_THREADS / LM::LPE;           // elements per workgroup pass
     XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);      // one entry per lane (its component(s))
-    const XYZZ<F> *X = in + (uint64_t)blockIdx.y * count;
+    const ACCMEM *X = in + (uint64_t)blockIdx.y * count;
     const uint32_t e = threadIdx.x / LM::LPE;
     const uint32_t i0 = blockIdx.x * (2u * NE) + e, i1 = i0 + NE;
     XYZZ<FR> acc = XYZZ<FR>::inf();
@@ -811,9 +851,9 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(XYZZ<F> *out
         __syncthreads();
     }
     if (e == 0) {
-        XYZZ<F> *dst = out + (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        if (last) LM::store256(dst, acc);    // back to the zkey's 2^256 form
-        else LM::store(dst, acc);
+        const uint64_t at = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (last) LM::store256(out_final + at, acc);    // window sums: canonical words, back in the zkey's 2^256 form
+        else LM::store(out + at, acc);
     }
 }
 
@@ -985,23 +1025,17 @@ uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
 }
 
 template <class F>
-static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32_t *entries, const Affine<F> *points,
+static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_t *entries, const Affine<F> *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
-                         XYZZ<F> *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
+                         ACCMEM *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
-    ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(XYZZ<F>), s));
+    ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(ACCMEM), s));
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
-        static const bool split = !(getenv("ZKHIP_G2_SPLIT") && atoi(getenv("ZKHIP_G2_SPLIT")) == 0);   // tuning aid
-        if (split)
-            hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
-                               points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
-                               accum_chunk_for(max_entries ? max_entries : 1));
-        else
-            hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
-                               points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
-                               accum_chunk_for(max_entries ? max_entries : 1));
+        hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
+                           points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
+                           accum_chunk_for(max_entries ? max_entries : 1));
     } else {
         hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
                            points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
@@ -1015,7 +1049,7 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
     }
     if (lanes > 1)
         hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256)), dim3(256), 0, s, buckets,
-                           (const XYZZ<F> *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
+                           (const ACCMEM *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
     uint64_t off = 0;
     while (lanes > 1) {          // a single unit has no cut runs: everything it saw was complete
         uint64_t items = 2 * lanes;
@@ -1030,19 +1064,19 @@ static void launch_accum(XYZZ<F> *buckets, const uint32_t *offsets, const uint32
     ZK_LAUNCH_OK("msm bucket accumulation");
 }
 
-void launch_msm_accum_g1(G1XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G1XYZZ *ws_part,
+void launch_msm_accum_g1(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G1Acc *ws_part,
                          uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
     launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
-void launch_msm_accum_g2(G2XYZZ *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2XYZZ *ws_part,
+void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
+                         uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2Acc *ws_part,
                          uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
     launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
 
 template <class F>
-static void launch_reduce(XYZZ<F> *window_sums, XYZZ<F> *scratch, const XYZZ<F> *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
+static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     uint32_t chunk = reduce_chunk_for(p);
     uint32_t cnt = p.nbuckets / chunk;
     const uint32_t groups = n_msm * p.sets;
@@ -1050,22 +1084,22 @@ static void launch_reduce(XYZZ<F> *window_sums, XYZZ<F> *scratch, const XYZZ<F> 
     hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks * LaneModel<F>::LPE + 127) / 128), dim3(128), 0, s, scratch, buckets, p.nbuckets, chunk, total_chunks);
     const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename LaneModel<F>::R>);
     const uint32_t TREE_IN = tree_in<F>();
-    XYZZ<F> *in = scratch;
+    ACCMEM *in = scratch;
     for (;;) {
         uint32_t blocks = (cnt + TREE_IN - 1) / TREE_IN;
         bool last = blocks == 1;
-        XYZZ<F> *out = last ? window_sums : in + (uint64_t)groups * cnt;
-        hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(blocks, groups), dim3(REDUCE_THREADS), lds, s, out, (const XYZZ<F> *)in, cnt, last ? 1u : 0u);
+        ACCMEM *out = in + (uint64_t)groups * cnt;
+        hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(blocks, groups), dim3(REDUCE_THREADS), lds, s, out, window_sums, (const ACCMEM *)in, cnt, last ? 1u : 0u);
         if (last) break;
         in = out;
         cnt = blocks;
     }
     ZK_LAUNCH_OK("msm bucket reduction");
 }
-void launch_msm_reduce_g1(G1XYZZ *ws, G1XYZZ *scratch, const G1XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
+void launch_msm_reduce_g1(G1XYZZ *ws, G1Acc *scratch, const G1Acc *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     launch_reduce<Fq>(ws, scratch, buckets, n_msm, p, s);
 }
-void launch_msm_reduce_g2(G2XYZZ *ws, G2XYZZ *scratch, const G2XYZZ *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
+void launch_msm_reduce_g2(G2XYZZ *ws, G2Acc *scratch, const G2Acc *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
     launch_reduce<Fq2>(ws, scratch, buckets, n_msm, p, s);
 }
 

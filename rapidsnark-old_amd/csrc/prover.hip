@@ -200,11 +200,13 @@ struct zk_prover {
     struct ProofSlot {
         bool allocated = false, busy = false;
         SortBufs sort_w;
-        DevBuf<G1XYZZ> buckets_g1;   // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
-        DevBuf<G2XYZZ> buckets_g2;
+        DevBuf<G1Acc> buckets_g1;    // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
+        DevBuf<G2Acc> buckets_g2;
         // accumulation workspaces, one per MSM: 0 = A, 1 = B1, 2 = C, 3 = H (G1), 4 = B2 (G2)
-        DevBuf<G1XYZZ> scratch_g1, wsum_g1, acc_ws_g1[4];
-        DevBuf<G2XYZZ> scratch_g2, wsum_g2, acc_ws_g2;
+        DevBuf<G1Acc> scratch_g1, acc_ws_g1[4];
+        DevBuf<G2Acc> scratch_g2, acc_ws_g2;
+        DevBuf<G1XYZZ> wsum_g1;
+        DevBuf<G2XYZZ> wsum_g2;
         DevBuf<uint32_t> acc_key[5], acc_flag[5];
         hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_f3 = nullptr, ev_f4 = nullptr,
@@ -632,7 +634,7 @@ struct PhaseCtx {
     uint32_t tbw, tbh, Ww;
     uint64_t ew, eh;
     MsmPlan pw;
-    G1XYZZ *bA, *bB1, *bC, *bH;
+    G1Acc *bA, *bB1, *bC, *bH;
     PhaseCtx(zk_prover *p_, int si) : p(p_), q(p_->slot[si]) {
         s = p->stream; s2 = p->stream2; s3 = p->stream3; s4 = p->stream4;
         tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
@@ -1328,7 +1330,7 @@ struct Tables {
     }
 };
 
-template <class AffT, class XT>
+template <class AffT, class XT, class AccT>
 static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scalars, uint64_t n, bool g2);
 
 extern "C" {
@@ -1422,7 +1424,7 @@ int zk_fr_abc_to_h(uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n) {
 
 }   // extern "C"
 
-template <class AffT, class XT>
+template <class AffT, class XT, class AccT>
 static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scalars, uint64_t n, bool g2) {
     need_device();
     if (n >= (1ull << 31)) throw std::invalid_argument("n too large");
@@ -1440,7 +1442,8 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     SortBufs sb;
     sb.alloc(n, 0);
     sb.run(sc.p, 0);
-    DevBuf<XT> buckets, scratch, wsum, ws;
+    DevBuf<AccT> buckets, scratch, ws;
+    DevBuf<XT> wsum;
     DevBuf<uint32_t> wkey, wflag;
     const uint64_t emax = sb.max_entries(), slots = msm_accum_workspace_slots(emax);
     ws.alloc(slots);
@@ -1451,11 +1454,11 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     wsum.alloc(sb.plan.sets);
     std::vector<uint8_t> w((size_t)sb.plan.sets * sizeof(XT));
     if constexpr (sizeof(AffT) == 64) {
-        launch_msm_accum_g1((G1XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G1XYZZ *)ws.p, wkey.p, wflag.p, 0);
-        launch_msm_reduce_g1((G1XYZZ *)wsum.p, (G1XYZZ *)scratch.p, (const G1XYZZ *)buckets.p, 1, sb.plan, 0);
+        launch_msm_accum_g1((G1Acc *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G1Acc *)ws.p, wkey.p, wflag.p, 0);
+        launch_msm_reduce_g1((G1XYZZ *)wsum.p, (G1Acc *)scratch.p, (const G1Acc *)buckets.p, 1, sb.plan, 0);
     } else {
-        launch_msm_accum_g2((G2XYZZ *)buckets.p, sb.offsets.p, sb.entries.p, (const G2Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G2XYZZ *)ws.p, wkey.p, wflag.p, 0);
-        launch_msm_reduce_g2((G2XYZZ *)wsum.p, (G2XYZZ *)scratch.p, (const G2XYZZ *)buckets.p, 1, sb.plan, 0);
+        launch_msm_accum_g2((G2Acc *)buckets.p, sb.offsets.p, sb.entries.p, (const G2Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G2Acc *)ws.p, wkey.p, wflag.p, 0);
+        launch_msm_reduce_g2((G2XYZZ *)wsum.p, (G2Acc *)scratch.p, (const G2Acc *)buckets.p, 1, sb.plan, 0);
     }
     HIP_TRY(hipMemcpy(w.data(), wsum.p, w.size(), hipMemcpyDeviceToHost));
     if (g2) HostTail::combine_windows_g2(w.data(), sb.plan.sets, sb.plan.c, out);
@@ -1518,10 +1521,10 @@ int zk_synth_chain_g2(uint8_t *out, uint64_t n, const uint8_t p0[128], const uin
 }
 
 int zk_msm_g1(uint8_t out[64], const uint8_t *bases, const uint8_t *scalars, uint64_t n) {
-    return guarded([&] { msm_generic<G1Affine, G1XYZZ>(out, bases, scalars, n, false); });
+    return guarded([&] { msm_generic<G1Affine, G1XYZZ, G1Acc>(out, bases, scalars, n, false); });
 }
 int zk_msm_g2(uint8_t out[128], const uint8_t *bases, const uint8_t *scalars, uint64_t n) {
-    return guarded([&] { msm_generic<G2Affine, G2XYZZ>(out, bases, scalars, n, true); });
+    return guarded([&] { msm_generic<G2Affine, G2XYZZ, G2Acc>(out, bases, scalars, n, true); });
 }
 
 }   // extern "C"

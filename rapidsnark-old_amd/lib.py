@@ -14,7 +14,8 @@ class ZkHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libzkhip.so")
+    # ZKHIP_LIB: another build of the same library (A/B measurements on one box); never a fallback
+    return os.environ.get("ZKHIP_LIB") or os.path.join(_HERE, "libzkhip.so")
 
 
 class zk_zkey_view(C.Structure):
