@@ -4,7 +4,7 @@ box).  Nothing here can be compared against a CPU proof in seconds, so the check
 size-independent ones the synthetic family was built for: every point table has KNOWN
 discrete logs, so each MSM result and the assembled proof are checked in Fr alone (three scalar
 multiplications on the host), h is cross-checked against the C restatement's FFT pipeline, and the
-NTT pass plans used at these sizes (11+6+5 and 11+7+6 bits) get round-trip / delta / linearity checks."""
+NTT pass plans used at these sizes (10+6+6 and 10+7+7 bits) get round-trip / delta / linearity checks."""
 import ctypes as C
 
 import numpy as np
@@ -101,7 +101,7 @@ def test_2p24_sharded8_on_one_gpu(zk):
 
 @pytest.mark.parametrize("logn", [22, 24])
 def test_ntt_properties_at_full_size(zk, logn):
-    """zk_fr_ntt at the domain sizes of configs[2]/[3] (pass plans 11+6+5 and 11+7+6): ifft(fft(x)) = x,
+    """zk_fr_ntt at the domain sizes of configs[2]/[3] (pass plans 10+6+6 and 10+7+7): ifft(fft(x)) = x,
     the transform of a delta at position j is the geometric sequence w^(j k), and linearity on a
     sample of outputs."""
     from rapidsnark_old_amd import synth
