@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1 (default, single GPU): consecutive proofs overlap through zk_prove_dev_submit / zk_prove_collect "
                          "(two in flight); 0: strictly one proof at a time (zk_prove_dev)")
-    ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = 3 with host witnesses, 2 with resident ones; max 3)")
+    ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = by size: 3 with host witnesses / 2 with resident ones from 2^19 up, 8 below; max 8)")
     ap.add_argument("--witness-in", choices=["host", "hbm"], default="host",
                     help="host (default): witnesses are pageable host arrays and every upload is timed (the reference's contract); "
                          "hbm: witnesses resident in HBM before the timed region")
@@ -75,7 +75,7 @@ def parse():
 
 def main():
     args = parse()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # six streams per prover (csrc/prover.hip); read when HIP initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # six streams per prover (csrc/prover.hip); read when HIP initialises
     import torch
     import rapidsnark_old_amd as zk
     from rapidsnark_old_amd import synth
@@ -186,7 +186,7 @@ def main():
             # i is collected, so its sort, SpMV and NTTs overlap proof i's reductions, D2H and host tail;
             # with host witnesses a third proof hides the upload (a proof cannot start before its witness
             # has arrived, and a slot is only free again after a collect)
-            depth = args.in_flight or (2 if in_hbm else 3)
+            depth = args.in_flight or default_depth(k, in_hbm)
             flying = 0
             for i in range(steps):
                 submit(warmup + i)
@@ -266,7 +266,7 @@ def main():
     # accumulation of MSM B2 (160 B per point).
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
-              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or (2 if headline_hbm else 3)) if pipelined else 1,
+              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm)) if pipelined else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
     pts_per_launch = n / world
@@ -308,6 +308,14 @@ def main():
     print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def default_depth(k, in_hbm):
+    """Proofs in flight per GPU: large circuits saturate the chip with two (three when the witness upload has to be
+    hidden); below 2^19 a proof is bound by the serial latency of its ~80 small kernels and more in flight fills the GPU."""
+    if k < 19:
+        return 8
+    return 2 if in_hbm else 3
 
 
 def traffic_from_profiles(args, config, world, which):

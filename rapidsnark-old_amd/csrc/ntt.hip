@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void k_build_tables(TwEntry *fwd, TwEntry *inv
         Fr wn = fr_root_of_unity(logn);
         s_wn = wn;
         s_wninv = Fr::inv(wn);
-        s_w2n = fr_root_of_unity(logn + 1);
+        // the coset needs a root of order 2n: none exists for n = 2^28 (2-adicity 28) — the table is then
+        // zero and never used (zk_prover_create and zk_fr_abc_to_h refuse such domains)
+        s_w2n = logn < 28 ? fr_root_of_unity(logn + 1) : Fr::zero();
         // n^-1: Montgomery form of n is to_mont(n)
         Fr nn = Fr::zero();
         nn.v[0] = (uint32_t)n;

@@ -31,10 +31,11 @@ using namespace zk;
 // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with streams aliased onto one queue the
 // witness upload of proof k+1 queued behind work of proof k and the proofs stopped overlapping —
 // measured at 2^22 with host witnesses: 44.2 ms per proof with 4 queues, 36.9 with 8 (resident
-// witnesses: 35.7).  The variable is read when the HIP runtime initialises, so this only helps when
+// witnesses: 35.7); four provers on one GPU (24 streams) collapse to 350 ms per 2^16 proof with 8 queues
+// and run at 2.2 ms with 16 or more, so the default asked for is 24 (no change at 2^22).  The variable is read when the HIP runtime initialises, so this only helps when
 // the library is loaded before the process's first HIP call; hosts should export it themselves
 // (INTEGRATION.md).  An explicit setting by the user is never overridden.
-__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 namespace {
 
@@ -651,7 +652,7 @@ struct PhaseCtx {
 
 int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32, hipEvent_t src_ready = nullptr) {
     DeviceGuard g(p->device);
-    if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("three proofs already in flight: collect one first");
+    if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("too many proofs in flight (ZK_MAX_IN_FLIGHT): collect one first");
     if (p->phase_open >= 0) throw std::invalid_argument("a proof is still being submitted phase by phase");
     const int si = (int)(p->next_submit % ZK_MAX_IN_FLIGHT);
     alloc_slot(p, si);
@@ -1129,7 +1130,7 @@ void multi_submit(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, 
     std::vector<std::unique_lock<std::mutex>> locks;
     for (zk_prover *q : mp->shard) locks.emplace_back(q->mtx);
     zk_prover *p0 = mp->shard[0];
-    if (p0->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("three proofs already in flight: collect one first");
+    if (p0->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("too many proofs in flight (ZK_MAX_IN_FLIGHT): collect one first");
     // the witness goes to every GPU (each needs all of it for its rows of A.w / B.w): staged ONCE into
     // pinned memory (host function on shard 0's upload stream), then G DMA copies
     const uint8_t *src = wtns;

@@ -334,8 +334,10 @@ void FullProver::deviceLoop(size_t worker) {
             }
         }
         if (job) {
-            // a prover holds at most ZK_MAX_IN_FLIGHT proofs: make room on that circuit's replica first
-            while (flying[job->circuit].size() >= ZK_MAX_IN_FLIGHT) finishOldest(job->circuit);
+            // depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs
+            // GiBs of workspace); small circuits are latency-bound per proof and want the maximum
+            const size_t depth = circuits[job->circuit].header->domainSize >= (1u << 19) ? 3 : ZK_MAX_IN_FLIGHT;
+            while (flying[job->circuit].size() >= depth) finishOldest(job->circuit);
             try {
                 circuits[job->circuit].replica[worker]->submit(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr);
                 flying[job->circuit].push_back(job);
