@@ -61,6 +61,7 @@ def parse():
                     help="1 (default, single GPU): consecutive proofs overlap through zk_prove_dev_submit / zk_prove_collect "
                          "(two in flight); 0: strictly one proof at a time (zk_prove_dev)")
     ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = by size: 3 with host witnesses / 2 with resident ones from 2^19 up, 8 below; max 8)")
+    ap.add_argument("--collector-thread", type=int, default=1, help="N = 1: collect on a second host thread (1, default) or in the submitting thread (0)")
     ap.add_argument("--witness-in", choices=["host", "hbm"], default="host",
                     help="host (default): witnesses are pageable host arrays and every upload is timed (the reference's contract); "
                          "hbm: witnesses resident in HBM before the timed region")
@@ -187,18 +188,52 @@ def main():
             # with host witnesses a third proof hides the upload (a proof cannot start before its witness
             # has arrived, and a slot is only free again after a collect)
             depth = args.in_flight or default_depth(k, in_hbm)
-            flying = 0
-            for i in range(steps):
-                submit(warmup + i)
-                flying += 1
-                if flying == depth:
+            if world == 1 and args.collector_thread:
+                # two host threads, as a server would run them: this one submits, the other collects (wait for
+                # the GPU + ≈1 ms of host tail per proof: Horner over the window sums, final assembly).  The
+                # library holds its submission mutex only around bookkeeping during a collect; ctypes drops
+                # the GIL for both calls.
+                import threading
+                free = threading.Semaphore(depth)
+                errors = []
+
+                def collector():
+                    try:
+                        for _ in range(steps):
+                            collect()
+                            add_timings()
+                            free.release()
+                    except Exception as exc:              # noqa: BLE001
+                        errors.append(exc)
+                        for _ in range(steps):
+                            free.release()
+
+                th = threading.Thread(target=collector)
+                started = False
+                for i in range(steps):
+                    free.acquire()
+                    if errors:
+                        break
+                    submit(warmup + i)
+                    if not started:
+                        th.start()
+                        started = True
+                th.join()
+                if errors:
+                    raise errors[0]
+            else:
+                flying = 0
+                for i in range(steps):
+                    submit(warmup + i)
+                    flying += 1
+                    if flying == depth:
+                        collect()
+                        add_timings()
+                        flying -= 1
+                while flying:
                     collect()
                     add_timings()
                     flying -= 1
-            while flying:
-                collect()
-                add_timings()
-                flying -= 1
         else:
             for i in range(steps):
                 submit(warmup + i)
@@ -267,6 +302,7 @@ def main():
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
               "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm)) if pipelined else 1,
+              "host_threads": 2 if (pipelined and world == 1 and args.collector_thread) else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
     pts_per_launch = n / world

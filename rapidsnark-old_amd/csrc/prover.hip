@@ -179,7 +179,12 @@ struct zk_prover {
     uint32_t shard_index = 0, shard_count = 1;
     uint8_t vk_alpha1[64], vk_beta1[64], vk_beta2[128], vk_delta1[64], vk_delta2[128];
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: witness-only MSM chain (A,B1,C,B2)
-    std::mutex mtx;
+    // mtx: submission + slot bookkeeping.  cmtx: serialises collectors; a collect holds mtx only to look the
+    // slot up and to retire it, NOT while it waits for the GPU and runs the host tail (≈ 1 ms of Horner +
+    // final assembly per proof: on small circuits that host time, not the GPU, bounds a one-thread
+    // submit/collect loop — a second thread collecting while the first submits removes it).
+    // sync_mtx: one synchronous zk_prove* call at a time.
+    std::mutex mtx, cmtx, sync_mtx;
 
     // resident data
     DevBuf<uint32_t> csr_rowptr, csr_col;
@@ -210,8 +215,8 @@ struct zk_prover {
         DevBuf<G2XYZZ> wsum_g2;
         DevBuf<uint32_t> acc_key[5], acc_flag[5];
         hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_f3 = nullptr, ev_f4 = nullptr,
-                   ev_done = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_done = nullptr;
+        hipEvent_t ev_tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev[20];      // 0-6 stage marks; 8/9, 13/14, 15/16, 17/18: G1 level-1 kernels of MSM A, B1, C, H; 10/11: G2; 12: upload
         bool have_events = false;
         uint8_t *w1 = nullptr, *w2 = nullptr;      // pinned host copies of the window sums
@@ -228,7 +233,8 @@ struct zk_prover {
         bool host_witness = false;
         ~ProofSlot() {
             for (auto &e : ev_l1) if (e) (void)hipEventDestroy(e);
-            for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_f3, ev_f4, ev_done}) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_done}) if (e) (void)hipEventDestroy(e);
+            for (auto &e : ev_tail) if (e) (void)hipEventDestroy(e);
             if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
             if (w1) (void)hipHostFree(w1);
             if (w2) (void)hipHostFree(w2);
@@ -253,7 +259,11 @@ struct zk_prover {
     int phase_open = -1, phase_next = 0;                 // slot being submitted phase by phase (-1: none), next phase
     hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;
     uint32_t log_shards_chain() const { return part ? log_shards : 0; }
-    hipStream_t stream3 = nullptr, stream4 = nullptr;   // follow-up streams of stream2 / stream: partial merges + bucket reductions
+    // follow-up streams: partial merges + bucket reductions of MSM m run on tail[m] (m: 0 = A, 1 = B1, 2 = C,
+    // 3 = H, 4 = B2); `tail_streams` distinct streams are shared among them (none = on the MSM's own stream)
+    hipStream_t tail_pool[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int tail_streams = 0;
     hipStream_t stream_fin = nullptr;                   // joins a proof's streams and copies its window sums to the host
     hipStream_t stream_h2d = nullptr;                   // witness uploads of host-witness proofs
 
@@ -262,14 +272,14 @@ struct zk_prover {
 
     ~zk_prover() {
         // proofs may still be in flight (submitted, never collected): drain before anything is released
-        for (hipStream_t st : {stream_h2d, stream, stream2, stream3, stream4, stream_fin})
+        for (hipStream_t st : {stream_h2d, stream, stream2, tail_pool[0], tail_pool[1], tail_pool[2], tail_pool[3], tail_pool[4], stream_fin})
             if (st) (void)hipStreamSynchronize(st);
         if (ev_ext_in) (void)hipEventDestroy(ev_ext_in);
         if (ev_ext_out) (void)hipEventDestroy(ev_ext_out);
         if (stream_h2d) (void)hipStreamDestroy(stream_h2d);
         if (stream_fin) (void)hipStreamDestroy(stream_fin);
-        if (stream3) (void)hipStreamDestroy(stream3);
-        if (stream4) (void)hipStreamDestroy(stream4);
+        for (hipStream_t st : tail_pool)
+            if (st) (void)hipStreamDestroy(st);
         if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -342,8 +352,9 @@ static void alloc_slot(zk_prover *p, int i) {
     HIP_TRY(hipHostMalloc((void **)&q.w1, q.w1_bytes, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&q.w2, q.w2_bytes, hipHostMallocDefault));
     for (auto &e : q.ev_l1) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t *e : {&q.ev_fork, &q.ev_join, &q.ev_sortw, &q.ev_main, &q.ev_f3, &q.ev_f4, &q.ev_done})
+    for (hipEvent_t *e : {&q.ev_fork, &q.ev_join, &q.ev_sortw, &q.ev_main, &q.ev_done})
         HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (auto &e : q.ev_tail) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : q.ev) HIP_TRY(hipEventCreate(&e));
     q.have_events = true;
     q.allocated = true;
@@ -430,14 +441,20 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         // pile up after the last one.  Measured with two proofs in flight: 2^22 39.7 -> 39.1 ms
         // (same box), 2^20 15.8 -> 13.5 ms, a shard of 8 at 2^22 12.4 -> 11.3 ms; one proof at a
         // time it is neutral from 2^20 up (2^18: 7.6 -> 8.0 ms).  ZKHIP_TAIL=0 turns them off.
+        // One follow-up stream PER MSM (five): with two (one per main stream) the tails of three MSMs
+        // queued on one stream, and on small circuits — where every kernel is latency-bound — that
+        // stream's 2.3 ms of serial merges and reductions per proof was the proof period at 2^16
+        // whatever the number of proofs in flight.  ZKHIP_TAIL=2 restores the two-stream layout.
         const char *e = getenv("ZKHIP_TAIL");
-        bool follow = e ? atoi(e) != 0 : true;
-        if (getenv("ZKHIP_SERIAL")) follow = false;
-        if (follow) {
+        int ntail = e ? atoi(e) : 5;
+        if (getenv("ZKHIP_SERIAL")) ntail = 0;
+        if (ntail != 0 && ntail != 2) ntail = 5;
+        p->tail_streams = ntail;
+        if (ntail) {
             int lo_pr = 0, hi_pr = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pr, &hi_pr));
-            HIP_TRY(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, hi_pr));
-            HIP_TRY(hipStreamCreateWithPriority(&p->stream4, hipStreamNonBlocking, hi_pr));
+            for (int i = 0; i < ntail; i++) HIP_TRY(hipStreamCreateWithPriority(&p->tail_pool[i], hipStreamNonBlocking, hi_pr));
+            for (int m = 0; m < 5; m++) p->tail[m] = ntail == 5 ? p->tail_pool[m] : p->tail_pool[(m == 2 || m == 3) ? 1 : 0];
         }
     }
     HIP_TRY(hipStreamCreateWithFlags(&p->stream_fin, hipStreamNonBlocking));
@@ -630,14 +647,14 @@ namespace {
 struct PhaseCtx {
     zk_prover *p;
     zk_prover::ProofSlot &q;
-    hipStream_t s, s2, s3, s4;
+    hipStream_t s, s2;
     bool tm;
     uint32_t tbw, tbh, Ww;
     uint64_t ew, eh;
     MsmPlan pw;
     G1Acc *bA, *bB1, *bC, *bH;
     PhaseCtx(zk_prover *p_, int si) : p(p_), q(p_->slot[si]) {
-        s = p->stream; s2 = p->stream2; s3 = p->stream3; s4 = p->stream4;
+        s = p->stream; s2 = p->stream2;
         tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
         tbw = q.sort_w.total_buckets(); tbh = p->sort_h.total_buckets();
         ew = q.sort_w.max_entries(); eh = p->sort_h.max_entries();
@@ -645,8 +662,8 @@ struct PhaseCtx {
         bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
     }
     void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
-    AccumTail tail_of(int m) const { AccumTail t; t.stream = (m == 2 || m == 3) ? s4 : s3; t.l1_done = q.ev_l1[m]; return t; }
-    hipStream_t after(hipStream_t own) const { return s4 ? s4 : own; }
+    AccumTail tail_of(int m) const { AccumTail t; t.stream = p->tail[m]; t.l1_done = q.ev_l1[m]; return t; }
+    hipStream_t after(int m, hipStream_t own) const { return p->tail[m] ? p->tail[m] : own; }
     NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
 };
 
@@ -665,7 +682,8 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     q.have_s = s32 != nullptr;
     if (r32) memcpy(q.r32, r32, 32);
     if (s32) memcpy(q.s32, s32, 32);
-    hipStream_t s = c.s, s2 = c.s2, s3 = c.s3;
+    hipStream_t s = c.s, s2 = c.s2;
+    const bool tails = p->tail_streams != 0;
     const bool tm = c.tm;
 
     c.mark(0);
@@ -688,12 +706,12 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     const uint64_t ew = c.ew;
     const MsmPlan pw = c.pw;
     launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4].p, q.acc_flag[4].p, s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
-    if (s3) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s3);
+    if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, p->tail[4]);
     launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0].p, q.acc_key[0].p, q.acc_flag[0].p, s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
-    if (s3) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, s3);
+    if (tails) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, p->tail[0]);
     launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1].p, q.acc_key[1].p, q.acc_flag[1].p, s2, tm ? &q.ev[13] : nullptr, c.tail_of(1));
-    if (s3) {
-        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, s3);
+    if (tails) {
+        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, p->tail[1]);
     } else {
         // bucket reductions stay on the stream of their MSMs
         launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
@@ -758,7 +776,7 @@ void phase_back(zk_prover *p) {
     DeviceGuard g(p->device);
     PhaseCtx c(p, p->phase_open);
     zk_prover::ProofSlot &q = c.q;
-    hipStream_t s = c.s, s3 = c.s3, s4 = c.s4;
+    hipStream_t s = c.s;
     const uint64_t nl = p->nloc;
     Fr *abc = p->abc_use;
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
@@ -769,13 +787,13 @@ void phase_back(zk_prover *p) {
     // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
     launch_msm_accum_g1(c.bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, c.tbh, c.eh, q.acc_ws_g1[3].p, q.acc_key[3].p, q.acc_flag[3].p, s, c.tm ? &q.ev[17] : nullptr, c.tail_of(3));
     c.mark(4);
-    launch_msm_reduce_g1(q.wsum_g1.p + 3 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, c.pw), c.bH, 1, p->sort_h.plan, c.after(s));
+    launch_msm_reduce_g1(q.wsum_g1.p + 3 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, c.pw), c.bH, 1, p->sort_h.plan, c.after(3, s));
     // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w).  (Moving it to
     // stream2 was measured slower at every shard count; so was raising stream 1's priority for
     // anything but the two-in-flight throughput of 4-8 shards.)
     HIP_TRY(hipStreamWaitEvent(s, q.ev_sortw, 0));
     launch_msm_accum_g1(c.bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, c.tbw, c.ew, q.acc_ws_g1[2].p, q.acc_key[2].p, q.acc_flag[2].p, s, c.tm ? &q.ev[15] : nullptr, c.tail_of(2));
-    launch_msm_reduce_g1(q.wsum_g1.p + 2 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, c.pw), c.bC, 1, c.pw, c.after(s));
+    launch_msm_reduce_g1(q.wsum_g1.p + 2 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, c.pw), c.bC, 1, c.pw, c.after(2, s));
     c.mark(5);
     HIP_TRY(hipEventRecord(q.ev_main, s));
 
@@ -784,11 +802,9 @@ void phase_back(zk_prover *p) {
     hipStream_t sf = p->stream_fin;
     HIP_TRY(hipStreamWaitEvent(sf, q.ev_main, 0));
     HIP_TRY(hipStreamWaitEvent(sf, q.ev_join, 0));
-    if (s3) {
-        HIP_TRY(hipEventRecord(q.ev_f3, s3));
-        HIP_TRY(hipStreamWaitEvent(sf, q.ev_f3, 0));
-        HIP_TRY(hipEventRecord(q.ev_f4, s4));
-        HIP_TRY(hipStreamWaitEvent(sf, q.ev_f4, 0));
+    for (int i = 0; i < p->tail_streams; i++) {
+        HIP_TRY(hipEventRecord(q.ev_tail[i], p->tail_pool[i]));
+        HIP_TRY(hipStreamWaitEvent(sf, q.ev_tail[i], 0));
     }
     if (c.tm) HIP_TRY(hipEventRecord(q.ev[6], sf));
     HIP_TRY(hipMemcpyAsync(q.w1, q.wsum_g1.p, q.w1_bytes, hipMemcpyDeviceToHost, sf));
@@ -821,18 +837,42 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns,
 }
 
 // Waits for the oldest proof in flight, then the host part: Horner over the window sums
-// (c doublings per window).  Caller holds p->mtx.
-static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out) {
-    if (!p->in_flight) throw std::invalid_argument("no proof in flight");
+// (c doublings per window).  Takes p->cmtx for the whole call and p->mtx only around the bookkeeping:
+// submissions go on while this thread waits and computes.  rs (optional) receives the proof's (r, s).
+struct SubmittedRS {
+    uint8_t r32[32], s32[32];
+    bool have_r = false, have_s = false;
+};
+static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullptr) {
+    std::lock_guard<std::mutex> ck(p->cmtx);
+    zk_prover::ProofSlot *qp;
+    {
+        std::lock_guard<std::mutex> lk(p->mtx);
+        if (!p->in_flight) throw std::invalid_argument("no proof in flight");
+        qp = &p->slot[p->next_collect % ZK_MAX_IN_FLIGHT];
+    }
+    zk_prover::ProofSlot &q = *qp;
     DeviceGuard g(p->device);
-    zk_prover::ProofSlot &q = p->slot[p->next_collect % ZK_MAX_IN_FLIGHT];
     const hipError_t done = hipEventSynchronize(q.ev_done);
-    // the slot is retired whatever happened (a failed proof must not wedge the queue), but only
-    // AFTER the wait: nobody may reuse its buffers while its kernels can still run
-    p->next_collect++;
-    p->in_flight--;
-    q.busy = false;
+    // the slot is retired whatever happens below (a failed proof must not wedge the queue), but only
+    // AFTER the wait and the host tail: nobody may reuse its buffers while they are still read
+    struct Retire {
+        zk_prover *p;
+        zk_prover::ProofSlot &q;
+        ~Retire() {
+            std::lock_guard<std::mutex> lk(p->mtx);
+            p->next_collect++;
+            p->in_flight--;
+            q.busy = false;
+        }
+    } retire{p, q};
     HIP_TRY(done);
+    if (rs) {
+        rs->have_r = q.have_r;
+        rs->have_s = q.have_s;
+        memcpy(rs->r32, q.r32, 32);
+        memcpy(rs->s32, q.s32, 32);
+    }
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
     if (tm) {
         float ms[7], g1 = 0, g2 = 0;
@@ -872,17 +912,19 @@ static zk_prover::ProofSlot &collect_sums_locked(zk_prover *p, zk_msm_sums *out)
     t2.join();
     t3.join();
     t4.join();
-    return q;
 }
 
 // One synchronous proof.  The witness upload, the device work and the wait all happen under the
 // prover's mutex: concurrent callers are serialised proof by proof (Prover::prove is re-entrant
 // in the reference; here the per-proof buffers are the prover's).
 void prove_msm(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, zk_msm_sums *out) {
-    std::lock_guard<std::mutex> lk(p->mtx);
-    if (p->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
-    submit_locked(p, d_wtns, h_wtns, nullptr, nullptr);
-    collect_sums_locked(p, out);
+    std::lock_guard<std::mutex> one(p->sync_mtx);
+    {
+        std::lock_guard<std::mutex> lk(p->mtx);
+        if (p->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
+        submit_locked(p, d_wtns, h_wtns, nullptr, nullptr);
+    }
+    collect_sums(p, out);
 }
 
 void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
@@ -988,8 +1030,7 @@ void zk_host_free(void *ptr) {
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial) {
     return guarded([&] {
         if (!p || !partial) throw std::invalid_argument("null argument");
-        std::lock_guard<std::mutex> lk(p->mtx);
-        collect_sums_locked(p, partial);
+        collect_sums(p, partial);
     });
 }
 
@@ -998,17 +1039,9 @@ int zk_prove_collect(zk_prover *p, zk_proof *out) {
         if (!p || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove_collect on a sharded prover: use zk_prove_msm_collect + zk_prove_finish");
         zk_msm_sums sums;
-        uint8_t r32[32], s32[32];
-        bool have_r, have_s;
-        {
-            std::lock_guard<std::mutex> lk(p->mtx);
-            zk_prover::ProofSlot &q = collect_sums_locked(p, &sums);
-            have_r = q.have_r;
-            have_s = q.have_s;
-            memcpy(r32, q.r32, 32);
-            memcpy(s32, q.s32, 32);
-        }
-        prove_finish(p, &sums, 1, have_r ? r32 : nullptr, have_s ? s32 : nullptr, out);
+        SubmittedRS rs;
+        collect_sums(p, &sums, &rs);
+        prove_finish(p, &sums, 1, rs.have_r ? rs.r32 : nullptr, rs.have_s ? rs.s32 : nullptr, out);
     });
 }
 
@@ -1052,7 +1085,7 @@ struct zk_multi_prover {
     StageJob stage[ZK_MAX_IN_FLIGHT];
     uint64_t submitted = 0;
     bool part = false;
-    std::mutex mtx;
+    std::mutex mtx, cmtx, sync_mtx;      // submit / collect / one synchronous call at a time (as in zk_prover)
     ~zk_multi_prover() {
         for (zk_prover *q : shard) zk_prover_destroy(q);        // drains every stream first
         for (auto &v : ev) for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e);
@@ -1184,20 +1217,9 @@ void multi_submit(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, 
 void multi_collect(zk_multi_prover *mp, zk_proof *out) {
     const size_t G = mp->shard.size();
     std::vector<zk_msm_sums> sums(G);
-    uint8_t r32[32], s32[32];
-    bool have_r = false, have_s = false;
-    for (size_t a = 0; a < G; a++) {
-        zk_prover *q = mp->shard[a];
-        std::lock_guard<std::mutex> lk(q->mtx);
-        zk_prover::ProofSlot &sl = collect_sums_locked(q, &sums[a]);
-        if (a == 0) {
-            have_r = sl.have_r;
-            have_s = sl.have_s;
-            memcpy(r32, sl.r32, 32);
-            memcpy(s32, sl.s32, 32);
-        }
-    }
-    prove_finish(mp->shard[0], sums.data(), (uint32_t)G, have_r ? r32 : nullptr, have_s ? s32 : nullptr, out);
+    SubmittedRS rs;
+    for (size_t a = 0; a < G; a++) collect_sums(mp->shard[a], &sums[a], a == 0 ? &rs : nullptr);
+    prove_finish(mp->shard[0], sums.data(), (uint32_t)G, rs.have_r ? rs.r32 : nullptr, rs.have_s ? rs.s32 : nullptr, out);
 }
 
 }   // namespace
@@ -1221,7 +1243,7 @@ int zk_multi_prove_submit(zk_multi_prover *mp, const uint8_t *wtns, const uint8_
 int zk_multi_prove_collect(zk_multi_prover *mp, zk_proof *out) {
     return guarded([&] {
         if (!mp || !out) throw std::invalid_argument("null argument");
-        std::lock_guard<std::mutex> lk(mp->mtx);
+        std::lock_guard<std::mutex> lk(mp->cmtx);          // submissions (mp->mtx) go on meanwhile
         multi_collect(mp, out);
     });
 }
@@ -1229,9 +1251,13 @@ int zk_multi_prove_collect(zk_multi_prover *mp, zk_proof *out) {
 int zk_multi_prove(zk_multi_prover *mp, const uint8_t *wtns, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
     return guarded([&] {
         if (!mp || !wtns || !out) throw std::invalid_argument("null argument");
-        std::lock_guard<std::mutex> lk(mp->mtx);
-        if (mp->shard[0]->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
-        multi_submit(mp, wtns, r32, s32);
+        std::lock_guard<std::mutex> one(mp->sync_mtx);
+        {
+            std::lock_guard<std::mutex> lk(mp->mtx);
+            if (mp->shard[0]->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
+            multi_submit(mp, wtns, r32, s32);
+        }
+        std::lock_guard<std::mutex> lk(mp->cmtx);
         multi_collect(mp, out);
     });
 }

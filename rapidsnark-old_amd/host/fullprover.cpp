@@ -298,63 +298,87 @@ void FullProver::witnessLoop() {
     }
 }
 
-// one per GPU: keeps up to ZK_MAX_IN_FLIGHT proofs in flight on its replicas (a collect returns the
-// oldest proof of THAT prover, so in-flight jobs are tracked per circuit)
+// Two threads per GPU.  The SUBMITTER takes ready jobs and enqueues their proofs (up to `depth` in flight per
+// circuit replica); the COLLECTOR retires them in submission order (a collect returns the oldest proof of
+// THAT prover, and the global FIFO preserves every prover's order): it waits for the GPU and runs the host
+// tail of a proof (Horner over the window sums + final assembly, ≈ 1 ms) while the submitter is already
+// enqueueing the next ones — on Semaphore-sized circuits the host time of a one-thread loop, not the GPU,
+// was the bound.
 void FullProver::deviceLoop(size_t worker) {
-    std::map<std::string, std::deque<JobPtr>> flying;
-    size_t nflying = 0;
+    std::mutex wm;
+    std::condition_variable cv;
+    std::deque<JobPtr> fifo;                       // submitted, not yet collected (submission order)
+    std::map<std::string, size_t> perCircuit;
+    bool submitterDone = false;
     uint8_t r[32], s[32];
     const bool haveR = scalarFromEnv("ZKHIP_FIXED_R", r), haveS = scalarFromEnv("ZKHIP_FIXED_S", s);
-    auto finishOldest = [&](const std::string &circuit) {
-        std::deque<JobPtr> &q = flying[circuit];
-        JobPtr job = q.front();
-        q.pop_front();
-        nflying--;
-        std::string proofJson, error;
-        try {
-            proofJson = circuits[circuit].replica[worker]->collect()->toJson();
-        } catch (std::exception &e) {
-            error = e.what();
+
+    std::thread collector([&] {
+        for (;;) {
+            JobPtr job;
+            {
+                std::unique_lock<std::mutex> lk(wm);
+                cv.wait(lk, [&] { return submitterDone || !fifo.empty(); });
+                if (fifo.empty()) return;
+                job = fifo.front();
+            }
+            std::string proofJson, error;
+            try {
+                proofJson = circuits[job->circuit].replica[worker]->collect()->toJson();
+            } catch (std::exception &e) {
+                error = e.what();
+            }
+            {
+                std::lock_guard<std::mutex> guard(mtx);
+                job->wtns.reset();
+                job->proof = error.empty() ? proofJson : "null";
+                job->error = error;
+                job->status = error.empty() ? success : failed;
+            }
+            {
+                std::lock_guard<std::mutex> lk(wm);
+                fifo.pop_front();
+                perCircuit[job->circuit]--;
+            }
+            cv.notify_all();
         }
-        std::lock_guard<std::mutex> guard(mtx);
-        job->wtns.reset();
-        job->proof = error.empty() ? proofJson : "null";
-        job->error = error;
-        job->status = error.empty() ? success : failed;
-    };
+    });
+
     for (;;) {
         JobPtr job;
         {
             std::unique_lock<std::mutex> lk(mtx);
-            if (nflying == 0) cvReady.wait(lk, [&] { return stopping || !readyJobs.empty(); });
-            if (stopping && nflying == 0) return;
-            if (!readyJobs.empty()) {
-                job = readyJobs.front();
-                readyJobs.pop_front();
-            }
+            cvReady.wait(lk, [&] { return stopping || !readyJobs.empty(); });
+            if (stopping) break;
+            job = readyJobs.front();
+            readyJobs.pop_front();
         }
-        if (job) {
-            // depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs
-            // GiBs of workspace); small circuits are latency-bound per proof and want the maximum
-            const size_t depth = circuits[job->circuit].header->domainSize >= (1u << 19) ? 3 : ZK_MAX_IN_FLIGHT;
-            while (flying[job->circuit].size() >= depth) finishOldest(job->circuit);
-            try {
-                circuits[job->circuit].replica[worker]->submit(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr);
-                flying[job->circuit].push_back(job);
-                nflying++;
-            } catch (std::exception &e) {
-                std::lock_guard<std::mutex> guard(mtx);
-                job->wtns.reset();
-                job->error = e.what();
-                job->status = failed;
-            }
-            continue;                // look for more work before blocking in a collect
+        // depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs GiBs of
+        // workspace); small circuits are latency-bound per proof and want the maximum
+        const size_t depth = circuits[job->circuit].header->domainSize >= (1u << 19) ? 3 : ZK_MAX_IN_FLIGHT;
+        {
+            std::unique_lock<std::mutex> lk(wm);
+            cv.wait(lk, [&] { return perCircuit[job->circuit] < depth; });
         }
-        // nothing new is ready: retire the oldest proof in flight (any circuit)
-        for (auto &kv : flying)
-            if (!kv.second.empty()) {
-                finishOldest(kv.first);
-                break;
+        try {
+            circuits[job->circuit].replica[worker]->submit(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr);
+            {
+                std::lock_guard<std::mutex> lk(wm);
+                fifo.push_back(job);
+                perCircuit[job->circuit]++;
             }
+            cv.notify_all();
+        } catch (std::exception &e) {
+            std::lock_guard<std::mutex> guard(mtx);
+            job->wtns.reset();
+            job->error = e.what();
+            job->status = failed;
+        }
     }
+    {
+        std::lock_guard<std::mutex> lk(wm);
+        submitterDone = true;
+    }
+    cv.notify_all();
+    collector.join();
 }
