@@ -857,7 +857,18 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out,
     }
 }
 
-static inline uint32_t reduce_chunk_for(MsmPlan p) { return p.nbuckets < REDUCE_CHUNK ? p.nbuckets : REDUCE_CHUNK; }
+// Buckets per lane of k_msm_reduce_chunks.  16 is the cheapest in total work (2 adds per bucket + one ~20-op
+// scalar multiplication per chunk); but a lane's chain is serial (32 + ~20 general adds of ~7 us each), and
+// with few buckets (small circuits, shards) the launch is a handful of waves whose latency — not work — is
+// what the proof waits for (2^16: 321 us per launch, the largest single item of a proof): smaller chunks
+// there (ZKHIP_REDUCE_CHUNK overrides, tuning aid).
+static inline uint32_t reduce_chunk_for(MsmPlan p) {
+    static const uint32_t forced = [] { const char *e = getenv("ZKHIP_REDUCE_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
+    uint32_t chunk = REDUCE_CHUNK;
+    if (forced) chunk = forced;
+    else if ((uint64_t)p.sets * p.nbuckets <= (1u << 16)) chunk = 4;
+    return p.nbuckets < chunk ? p.nbuckets : chunk;
+}
 
 // scratch: chunk sums + the intermediate levels of the tree (a geometric tail)
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
@@ -1005,7 +1016,8 @@ void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, 
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
 static inline uint32_t accum_chunk_for(uint64_t max_entries) {
     uint32_t chunk = ACC_CHUNK_MAX;
-    while (chunk > ACC_CHUNK_MIN && max_entries / chunk < 3u * 1024u * 64u) chunk >>= 1;   // 256 CUs x 4 SIMDs x 3 waves
+    static const uint32_t cmin = [] { const char *e = getenv("ZKHIP_ACC_CHUNK_MIN"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MIN; return v < 4u ? 4u : v; }();
+    while (chunk > cmin && max_entries / chunk < 3u * 1024u * 64u) chunk >>= 1;   // 256 CUs x 4 SIMDs x 3 waves
     return chunk;
 }
 static inline uint64_t accum_l1_lanes(uint64_t max_entries) {
