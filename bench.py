@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+ZK_DEPTH_MAX = 8               # ZK_MAX_IN_FLIGHT (include/zkhip.h)
 G1_MSM_BYTES_PER_POINT = 96    # 64 B affine point + 32 B scalar
 G2_MSM_BYTES_PER_POINT = 160   # 128 B affine G2 point + 32 B scalar
 
@@ -76,7 +77,7 @@ def parse():
 
 def main():
     args = parse()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # six streams per prover (csrc/prover.hip); read when HIP initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # six streams per prover (csrc/prover.hip); read when HIP initialises
     import torch
     import rapidsnark_old_amd as zk
     from rapidsnark_old_amd import synth
@@ -120,23 +121,31 @@ def main():
                             window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned)
     t_create = time.time() - t0
     chain = None
+    sliced_upload = False
     if partitioned:
         from rapidsnark_old_amd.dist import ShardedChain
 
         def exchange_via_cpu(dst, src):
-            # single-GPU test hook only (gloo): all_gather of the blocks on the host, then pick this rank's chunks
+            # single-GPU test hook only (gloo): all_gather of the send buffers on the host, then pick this rank's parts
             torch.cuda.synchronize()
             mine = src.cpu()
             allb = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(allb, mine)
-            ch = mine.shape[1] // world
-            out = torch.empty_like(mine)
-            for sidx in range(world):
-                out[:, sidx * ch:(sidx + 1) * ch] = allb[sidx][:, rank * ch:(rank + 1) * ch]
-            dst.copy_(out)
+            part = mine.numel() // world
+            dst.copy_(torch.cat([allb[sidx][rank * part:(rank + 1) * part] for sidx in range(world)]))
             torch.cuda.synchronize()
 
         chain = ShardedChain(prover.lib, prover.h, dist, dev, exchange=exchange_via_cpu if share else None)
+
+        def gather_via_cpu(full, part):                   # single-GPU test hook only (gloo)
+            torch.cuda.synchronize()
+            mine = part.cpu()
+            allp = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allp, mine)
+            full.copy_(torch.cat(allp))
+            torch.cuda.synchronize()
+
+        sliced_upload = chain.enable_sliced_upload(wl["nVars"], rank, world, ZK_DEPTH_MAX, dev, gather=gather_via_cpu if share else None)
 
     # --- distinct witnesses (same on every rank: seeded): pageable host arrays, and HBM copies of
     # the same for the resident-witness leg
@@ -154,6 +163,8 @@ def main():
             if chain is not None:                            # phases + four rounds of all_to_all (RCCL over xGMI)
                 if in_hbm:
                     chain.submit(d_wtns=wits_dev[j].data_ptr())
+                elif sliced_upload:                          # 1/N of the witness over PCIe per rank + all_gather over xGMI
+                    chain.submit_host_sliced(wits_host[j])
                 else:
                     chain.submit(wtns=wits_host[j])
             elif in_hbm:

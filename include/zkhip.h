@@ -160,18 +160,19 @@ int zk_multi_prove_collect(zk_multi_prover *mp, zk_proof *out);
 int zk_multi_prover_info(zk_multi_prover *mp, uint32_t *n_shards, uint32_t *chain_partitioned);
 /* (b) One process per GPU (torch.distributed over RCCL): a prover created with shard_index/shard_count and
  *     ZK_FLAG_PARTITIONED_CHAIN is driven step by step, and the CALLER moves the blocks between the steps
- *     with four all_to_all per proof on two buffers it owns and registers here (3 polynomials x block_elems
- *     x 32 bytes each; `abc` holds the three blocks, `xb` is the exchange buffer [poly][source GPU][chunk]):
- *         zk_shard_begin                      a, b, c blocks              -> all_to_all(xb[poly] <- abc[poly]) x3
- *         zk_shard_step(ZK_STEP_CROSS_INVERSE) top stages, in place in xb -> all_to_all(abc[poly] <- xb[poly]) x3
- *         zk_shard_step(ZK_STEP_LOCAL)         local stages + coset shift -> all_to_all(xb <- abc) x3
- *         zk_shard_step(ZK_STEP_CROSS_FORWARD) top stages, in place in xb -> all_to_all(abc <- xb) x3
- *         zk_shard_step(ZK_STEP_FINISH)        h, MSM H, MSM C, joins     -> zk_prove_msm_collect + zk_prove_finish
+ *     with FOUR all_to_all_single per proof on two buffers it owns and registers here (3 polynomials x
+ *     block_elems x 32 bytes each, both laid out [GPU][polynomial][chunk]: `send` is what the library packs
+ *     for / unpacks from the collective, `recv` is what the cross stages work on in place):
+ *         zk_shard_begin                       rows of a, b, c; packed -> send     all_to_all_single(recv <- send)
+ *         zk_shard_step(ZK_STEP_CROSS_INVERSE) top stages in place in recv         all_to_all_single(send <- recv)
+ *         zk_shard_step(ZK_STEP_LOCAL)         unpack, local stages + coset, pack  all_to_all_single(recv <- send)
+ *         zk_shard_step(ZK_STEP_CROSS_FORWARD) top stages in place in recv         all_to_all_single(send <- recv)
+ *         zk_shard_step(ZK_STEP_FINISH)        unpack, h, MSM H, MSM C, joins      zk_prove_msm_collect + zk_prove_finish
  *     `stream` (hipStream_t; NULL = the default stream) is the stream the caller's collectives are ordered
  *     on: every call first waits for what is enqueued on it and makes it wait for what the call enqueued. */
 enum { ZK_STEP_CROSS_INVERSE = 1, ZK_STEP_LOCAL = 2, ZK_STEP_CROSS_FORWARD = 3, ZK_STEP_FINISH = 4 };
 int zk_shard_info(zk_prover *p, uint64_t *block_elems, uint32_t *chain_partitioned);
-int zk_shard_set_exchange(zk_prover *p, void *d_abc, void *d_xb);
+int zk_shard_set_exchange(zk_prover *p, void *d_send, void *d_recv);
 int zk_shard_begin(zk_prover *p, const uint8_t *wtns, const void *d_wtns, const uint8_t *r32, const uint8_t *s32, void *stream);
 int zk_shard_step(zk_prover *p, int step, void *stream);
 

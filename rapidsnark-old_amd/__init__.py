@@ -5,7 +5,7 @@ mirror of the reference's binfile/zkey/wtns readers.  There is no Python/CPU com
 fallback: if libzkhip.so is missing or HIP has no device, calls raise.
 """
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # before the first HIP call of the process (lib.py: load_library)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the first HIP call of the process (lib.py: load_library)
 from .binfile import BinFile, open_existing            # noqa: F401
 from .zkey import ZkeyHeader, load_zkey_header          # noqa: F401
 from .wtns import WtnsHeader, load_wtns_header          # noqa: F401

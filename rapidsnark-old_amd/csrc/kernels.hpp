@@ -58,13 +58,19 @@ void launch_ntt_dif_inverse(Fr *data, uint64_t stride_elems, uint32_t batch, con
 void launch_ntt_dit_forward(Fr *data, uint64_t stride_elems, uint32_t batch, const NttTables &t, hipStream_t s, const Fr *premul = nullptr,
                             uint32_t local_logn = NTT_FULL);
 // The stages over the TOP log_shards index bits of a transform partitioned across G = 2^log_shards GPUs
-// (see ntt.hip): xb = this GPU's exchange buffer [batch][G][n/G^2]; the result for block s is written to
-// out_base[s] + poly*out_poly_stride + out_offset + o'.  inverse: DIF stages + inverse twiddles.
-void launch_ntt_cross(bool inverse, const Fr *xb, Fr *const out_base[8], uint64_t out_poly_stride, uint64_t out_offset, uint32_t batch,
+// (see ntt.hip).  xb = this GPU's exchange buffer: element o' of polynomial `poly` of source GPU s sits at
+// xb[s*in_src_stride + poly*in_poly_stride + o'] ([poly][G][n/G^2] inside one process, [G][poly][n/G^2] on the
+// all_to_all path); the result for block s is written to out_base[s] + poly*out_poly_stride + out_offset + o'.
+// inverse: DIF stages + inverse twiddles.
+void launch_ntt_cross(bool inverse, const Fr *xb, uint64_t in_src_stride, uint64_t in_poly_stride, Fr *const out_base[8],
+                      uint64_t out_poly_stride, uint64_t out_offset, uint32_t batch,
                       const NttTables &t, uint32_t log_shards, uint32_t rank, hipStream_t s);
 // chunk s of every polynomial of this GPU's block (batch x n/G elements) -> slot `rank` of xb_of_gpu[s]
 void launch_chunk_scatter(Fr *const xb_of_gpu[8], const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, uint32_t rank,
                           hipStream_t s);
+// block <-> one contiguous buffer [GPU][poly][n/G^2] (what ONE all_to_all_single sends / delivers)
+void launch_chunk_pack(Fr *packed, const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, hipStream_t s);
+void launch_chunk_unpack(Fr *blockdata, const Fr *packed, uint32_t batch, uint32_t logn, uint32_t log_shards, hipStream_t s);
 // Fr vectors: x*2^256 (zkey/ffiasm Montgomery form) -> x*2^(256+5*times) ; and 2^261 -> 2^256.
 // The NTT / SpMV kernels work on canonical words of the 2^261 form (field29.hpp).
 void launch_fr_to_internal(Fr *x, uint64_t n, int times, hipStream_t s);

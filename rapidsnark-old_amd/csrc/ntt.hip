@@ -242,17 +242,18 @@ struct CrossOut {
 };
 
 template <bool DIF, int LG>
-__global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, CrossOut out, uint64_t out_poly_stride, uint64_t out_offset,
+__global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, uint64_t in_src_stride, uint64_t in_poly_stride, CrossOut out,
+                                                   uint64_t out_poly_stride, uint64_t out_offset,
                                                    const TwEntry *tw, uint32_t logn, uint32_t rank, uint64_t chunk, uint64_t block) {
     constexpr int G = 1 << LG;
     const uint64_t op = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // offset inside this GPU's chunk
     if (op >= chunk) return;
     const uint32_t poly = blockIdx.y;
-    const Fr *src = xb + (uint64_t)poly * block + op;
+    const Fr *src = xb + (uint64_t)poly * in_poly_stride + op;
     const uint64_t o = (uint64_t)rank * chunk + op;                             // offset inside a block
     Fr29 x[G];
 #pragma unroll
-    for (int sidx = 0; sidx < G; sidx++) x[sidx] = Fr29::load(load_el(src + (uint64_t)sidx * chunk));
+    for (int sidx = 0; sidx < G; sidx++) x[sidx] = Fr29::load(load_el(src + (uint64_t)sidx * in_src_stride));
 #pragma unroll
     for (int t = 0; t < LG; t++) {
         // DIF: bit b = logn-1-t, partner differs in block bit LG-1-t; DIT: b = logn-LG+t, block bit t
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, CrossOut out, u
         store_el(out.base[sidx] + (uint64_t)poly * out_poly_stride + out_offset + op, Fr29::store(x[sidx]));
 }
 
-void launch_ntt_cross(bool inverse, const Fr *xb, Fr *const out_base[8], uint64_t out_poly_stride, uint64_t out_offset, uint32_t batch,
+void launch_ntt_cross(bool inverse, const Fr *xb, uint64_t in_src_stride, uint64_t in_poly_stride, Fr *const out_base[8],
+                      uint64_t out_poly_stride, uint64_t out_offset, uint32_t batch,
                       const NttTables &tb, uint32_t log_shards, uint32_t rank, hipStream_t s) {
     if (log_shards == 0) return;
     const uint64_t block = 1ull << (tb.logn - log_shards), chunk = block >> log_shards;
@@ -290,7 +292,7 @@ void launch_ntt_cross(bool inverse, const Fr *xb, Fr *const out_base[8], uint64_
     for (int i = 0; i < 8; i++) out.base[i] = i < (1 << log_shards) ? out_base[i] : nullptr;
     const dim3 grid((uint32_t)((chunk + 255) / 256), batch), blk(256);
     const TwEntry *tw = inverse ? tb.inv : tb.fwd;
-#define ZK_CROSS(D, L) hipLaunchKernelGGL((k_ntt_cross<D, L>), grid, blk, 0, s, xb, out, out_poly_stride, out_offset, tw, tb.logn, rank, chunk, block)
+#define ZK_CROSS(D, L) hipLaunchKernelGGL((k_ntt_cross<D, L>), grid, blk, 0, s, xb, in_src_stride, in_poly_stride, out, out_poly_stride, out_offset, tw, tb.logn, rank, chunk, block)
     if (inverse) {
         if (log_shards == 1) ZK_CROSS(true, 1); else if (log_shards == 2) ZK_CROSS(true, 2); else ZK_CROSS(true, 3);
     } else {
@@ -305,20 +307,45 @@ void launch_ntt_cross(bool inverse, const Fr *xb, Fr *const out_base[8], uint64_
 struct ChunkDst {
     Fr *base[8];
 };
-__global__ __launch_bounds__(256) void k_chunk_scatter(ChunkDst dst, const Fr *blockdata, uint64_t chunk, uint64_t block, uint32_t rank) {
+// chunk c of polynomial `poly` of this GPU's block  <->  dst.base[c] + poly*poly_stride + offset (+ position in the chunk)
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_chunk_move(ChunkDst far, Fr *blockdata, uint64_t chunk, uint64_t block, uint64_t poly_stride, uint64_t offset) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element inside this GPU's block
     if (i >= block) return;
     const uint32_t poly = blockIdx.y;
     const uint64_t sidx = i / chunk, op = i - sidx * chunk;
-    store_el(dst.base[sidx] + (uint64_t)poly * block + (uint64_t)rank * chunk + op, load_el(blockdata + (uint64_t)poly * block + i));
+    Fr *there = far.base[sidx] + (uint64_t)poly * poly_stride + offset + op, *here = blockdata + (uint64_t)poly * block + i;
+    if (GATHER) store_el(here, load_el(there));
+    else store_el(there, load_el(here));
+}
+static void chunk_move(bool gather, Fr *const far_base[8], Fr *blockdata, uint64_t poly_stride, uint64_t offset, uint32_t batch, uint32_t logn,
+                       uint32_t log_shards, hipStream_t s) {
+    const uint64_t block = 1ull << (logn - log_shards), chunk = block >> log_shards;
+    ChunkDst d;
+    for (int i = 0; i < 8; i++) d.base[i] = i < (1 << log_shards) ? far_base[i] : nullptr;
+    const dim3 grid((uint32_t)((block + 255) / 256), batch);
+    if (gather) hipLaunchKernelGGL(k_chunk_move<true>, grid, dim3(256), 0, s, d, blockdata, chunk, block, poly_stride, offset);
+    else hipLaunchKernelGGL(k_chunk_move<false>, grid, dim3(256), 0, s, d, blockdata, chunk, block, poly_stride, offset);
+    ZK_LAUNCH_OK("chunk scatter/gather");
 }
 void launch_chunk_scatter(Fr *const xb_of_gpu[8], const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, uint32_t rank,
                           hipStream_t s) {
     const uint64_t block = 1ull << (logn - log_shards), chunk = block >> log_shards;
-    ChunkDst d;
-    for (int i = 0; i < 8; i++) d.base[i] = i < (1 << log_shards) ? xb_of_gpu[i] : nullptr;
-    hipLaunchKernelGGL(k_chunk_scatter, dim3((uint32_t)((block + 255) / 256), batch), dim3(256), 0, s, d, blockdata, chunk, block, rank);
-    ZK_LAUNCH_OK("chunk scatter");
+    chunk_move(false, xb_of_gpu, const_cast<Fr *>(blockdata), block, (uint64_t)rank * chunk, batch, logn, log_shards, s);
+}
+// one-process-per-GPU path: the block <-> ONE contiguous buffer laid out [destination / source GPU][poly][chunk], so that
+// a single all_to_all_single moves all three polynomials
+void launch_chunk_pack(Fr *packed, const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, hipStream_t s) {
+    const uint64_t chunk = (1ull << (logn - log_shards)) >> log_shards;
+    Fr *base[8];
+    for (int i = 0; i < 8; i++) base[i] = packed + (uint64_t)i * batch * chunk;
+    chunk_move(false, base, const_cast<Fr *>(blockdata), chunk, 0, batch, logn, log_shards, s);
+}
+void launch_chunk_unpack(Fr *blockdata, const Fr *packed, uint32_t batch, uint32_t logn, uint32_t log_shards, hipStream_t s) {
+    const uint64_t chunk = (1ull << (logn - log_shards)) >> log_shards;
+    Fr *base[8];
+    for (int i = 0; i < 8; i++) base[i] = const_cast<Fr *>(packed) + (uint64_t)i * batch * chunk;
+    chunk_move(true, base, blockdata, chunk, 0, batch, logn, log_shards, s);
 }
 
 // ------------------------------------------------------------------ pointwise helpers

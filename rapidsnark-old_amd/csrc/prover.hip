@@ -32,10 +32,11 @@ using namespace zk;
 // witness upload of proof k+1 queued behind work of proof k and the proofs stopped overlapping —
 // measured at 2^22 with host witnesses: 44.2 ms per proof with 4 queues, 36.9 with 8 (resident
 // witnesses: 35.7); four provers on one GPU (24 streams) collapse to 350 ms per 2^16 proof with 8 queues
-// and run at 2.2 ms with 16 or more, so the default asked for is 24 (no change at 2^22).  The variable is read when the HIP runtime initialises, so this only helps when
+// and run at 2.2 ms with 16 or more, so the default asked for is 16 (no change at 2^22; the GPU has ~24
+// hardware queue slots for ALL processes: beyond them the driver time-slices queues, so not more).  The variable is read when the HIP runtime initialises, so this only helps when
 // the library is loaded before the process's first HIP call; hosts should export it themselves
 // (INTEGRATION.md).  An explicit setting by the user is never overridden.
-__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 namespace {
 
@@ -253,7 +254,8 @@ struct zk_prover {
     uint32_t log_shards = 0;
     uint64_t nloc = 0;                                   // rows of a, b, c, h held here (= domainSize unless part)
     DevBuf<Fr> xb;                                       // exchange buffer of the cross stages: [3][shard][nloc / shards]
-    Fr *abc_use = nullptr, *xb_use = nullptr;            // own buffers, or the caller's (zk_shard_set_exchange)
+    Fr *abc_use = nullptr, *xb_use = nullptr;            // a|b|c blocks; exchange buffer (own, or the caller's: zk_shard_set_exchange)
+    Fr *pk_use = nullptr;                                // caller's send/receive staging [GPU][poly][chunk] (all_to_all path only)
     Fr *peer_abc[8] = {nullptr}, *peer_xb[8] = {nullptr};   // inside one process: every shard's buffers (zk_multi_prover)
     bool have_peers = false;
     int phase_open = -1, phase_next = 0;                 // slot being submitted phase by phase (-1: none), next phase
@@ -726,6 +728,7 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
     launch_spmv_abc(abc, abc + nl, abc + 2 * nl, csr, d_wtns, (uint32_t)nl, s);
     c.mark(1);
+    if (p->part && !p->have_peers && p->pk_use) launch_chunk_pack(p->pk_use, abc, 3, p->logn, p->log_shards, s);   // -> all_to_all #1
     p->phase_open = si;
     p->phase_next = p->part ? 1 : 2;
     return si;
@@ -746,12 +749,14 @@ void phase_cross_run(zk_prover *p, bool inverse, hipEvent_t done) {
     PhaseCtx c(p, p->phase_open);
     const uint64_t nl = p->nloc, chunk = nl >> p->log_shards;
     if (p->have_peers) {
-        // results go straight into the owners' blocks (peer writes)
-        launch_ntt_cross(inverse, p->xb_use, p->peer_abc, nl, (uint64_t)p->shard_index * chunk, 3, c.tables(), p->log_shards, p->shard_index, c.s);
+        // exchange buffer [poly][source GPU][chunk]; results go straight into the owners' blocks (peer writes)
+        launch_ntt_cross(inverse, p->xb_use, chunk, nl, p->peer_abc, nl, (uint64_t)p->shard_index * chunk, 3, c.tables(), p->log_shards, p->shard_index, c.s);
     } else {
+        // exchange buffer [source GPU][poly][chunk] (one all_to_all_single delivered it); results in place
+        if (!p->pk_use) throw std::invalid_argument("no exchange buffers registered (zk_shard_set_exchange)");
         Fr *inplace[8];
-        for (uint32_t i = 0; i < 8; i++) inplace[i] = p->xb_use + (uint64_t)i * chunk;
-        launch_ntt_cross(inverse, p->xb_use, inplace, nl, 0, 3, c.tables(), p->log_shards, p->shard_index, c.s);
+        for (uint32_t i = 0; i < 8; i++) inplace[i] = p->xb_use + (uint64_t)i * 3 * chunk;
+        launch_ntt_cross(inverse, p->xb_use, 3 * chunk, chunk, inplace, chunk, 0, 3, c.tables(), p->log_shards, p->shard_index, c.s);
     }
     if (done) HIP_TRY(hipEventRecord(done, c.s));
     p->phase_next = inverse ? 2 : 4;
@@ -766,8 +771,11 @@ void phase_local(zk_prover *p) {
     const uint32_t local_logn = p->logn - p->log_shards_chain();
     const uint64_t nl = p->nloc;
     NttTables tb = c.tables();
+    const bool a2a = p->part && !p->have_peers;          // blocks travel through the caller's all_to_all
+    if (a2a) launch_chunk_unpack(p->abc_use, p->pk_use, 3, p->logn, p->log_shards, c.s);
     launch_ntt_dif_inverse(p->abc_use, nl, 3, tb, c.s, local_logn);
     launch_ntt_dit_forward(p->abc_use, nl, 3, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
+    if (a2a) launch_chunk_pack(p->pk_use, p->abc_use, 3, p->logn, p->log_shards, c.s);
     p->phase_next = p->part ? 3 : 4;
 }
 
@@ -779,6 +787,7 @@ void phase_back(zk_prover *p) {
     hipStream_t s = c.s;
     const uint64_t nl = p->nloc;
     Fr *abc = p->abc_use;
+    if (p->part && !p->have_peers) launch_chunk_unpack(abc, p->pk_use, 3, p->logn, p->log_shards, s);
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
     launch_abc_to_h(p->h.p, abc, abc + nl, abc + 2 * nl, nl, s);
     c.mark(2);
@@ -1278,15 +1287,14 @@ int zk_shard_info(zk_prover *p, uint64_t *block_elems, uint32_t *chain_partition
     });
 }
 
-int zk_shard_set_exchange(zk_prover *p, void *d_abc, void *d_xb) {
+int zk_shard_set_exchange(zk_prover *p, void *d_send, void *d_recv) {
     return guarded([&] {
-        if (!p || !d_abc || !d_xb) throw std::invalid_argument("null argument");
+        if (!p || !d_send || !d_recv) throw std::invalid_argument("null argument");
         std::lock_guard<std::mutex> lk(p->mtx);
         if (!p->part) throw std::invalid_argument("prover was not created with ZK_FLAG_PARTITIONED_CHAIN");
         if (p->in_flight || p->phase_open >= 0) throw std::invalid_argument("proofs in flight");
-        p->abc_use = (Fr *)d_abc;
-        p->xb_use = (Fr *)d_xb;
-        p->abc.release();
+        p->pk_use = (Fr *)d_send;
+        p->xb_use = (Fr *)d_recv;
         p->xb.release();
     });
 }

@@ -23,8 +23,8 @@ def gather_partials(partial: bytes, dist, device):
 
 class ShardedChain:
     """One rank of a proof whose chain (A.w/B.w rows + the six transforms) is PARTITIONED across the
-    ranks (include/zkhip.h, zk_shard_*): the library computes, this class moves the blocks — four rounds
-    of all_to_all per proof (three polynomials each) on two torch tensors registered with the prover.
+    ranks (include/zkhip.h, zk_shard_*): the library computes, this class moves the blocks — four
+    all_to_all_single per proof on two torch tensors registered with the prover.
     `dist` is torch.distributed (backend nccl = RCCL over xGMI); `exchange(dst, src)` can be replaced for
     tests (e.g. staging through the CPU for gloo)."""
 
@@ -37,15 +37,42 @@ class ShardedChain:
         if not part.value:
             raise ValueError("prover was not created with ZK_FLAG_PARTITIONED_CHAIN")
         self.nloc = nloc.value
-        # [poly][block] as bytes; a block is split into world_size equal chunks by all_to_all_single
-        self.abc = torch.zeros((3, self.nloc * 32), dtype=torch.uint8, device=device)
-        self.xb = torch.zeros((3, self.nloc * 32), dtype=torch.uint8, device=device)
-        L.check(lib.zk_shard_set_exchange(handle, C.c_void_p(self.abc.data_ptr()), C.c_void_p(self.xb.data_ptr())))
+        # both buffers: [GPU][polynomial][chunk] as bytes — all_to_all_single splits them into world_size equal parts
+        self.send = torch.zeros(3 * self.nloc * 32, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(3 * self.nloc * 32, dtype=torch.uint8, device=device)
+        L.check(lib.zk_shard_set_exchange(handle, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr())))
         self.exchange = exchange or self._all_to_all
 
     def _all_to_all(self, dst, src):
-        for poly in range(3):
-            self.dist.all_to_all_single(dst[poly], src[poly])
+        self.dist.all_to_all_single(dst, src)
+
+    def enable_sliced_upload(self, n_vars, rank, world, depth, device, gather=None):
+        """Host witnesses: every rank uploads only ITS 1/world of the witness over PCIe and the ranks
+        all_gather the rest over xGMI (every GPU needs the whole vector: the rows of A.w / B.w gather random
+        columns).  Without this each rank stages and uploads all of it — world x the host-memory traffic, and
+        at 8 ranks the 128 MiB upload of a 2^22 witness (staging 5 ms + DMA 2.6 ms) is as long as the proof
+        period.  `depth` buffers rotate (one per proof in flight).  `gather(full, part)` replaces
+        dist.all_gather_into_tensor in tests."""
+        nbytes = n_vars * 32
+        if nbytes % world:
+            return False
+        self._sl = (rank * (nbytes // world), (rank + 1) * (nbytes // world))
+        self._wfull = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self._wpart = [torch.empty(nbytes // world, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self._wpin = [torch.empty(nbytes // world, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self._wk = 0
+        self._gather = gather or (lambda full, part: self.dist.all_gather_into_tensor(full, part))
+        return True
+
+    def submit_host_sliced(self, wtns, r=None, s=None):
+        """wtns: the whole witness as a numpy uint8 array in host memory (identical on every rank)."""
+        k = self._wk % len(self._wfull)
+        self._wk += 1
+        lo, hi = self._sl
+        self._wpin[k].copy_(torch.from_numpy(wtns[lo:hi]))            # pageable -> pinned, 1/world of the witness
+        self._wpart[k].copy_(self._wpin[k], non_blocking=True)        # PCIe, on the current stream
+        self._gather(self._wfull[k], self._wpart[k])                  # xGMI
+        self.submit(d_wtns=self._wfull[k].data_ptr(), r=r, s=s)
 
     def submit(self, wtns=None, d_wtns=None, r=None, s=None):
         """Enqueue one proof: wtns = host numpy uint8 array (kept alive by the caller until collected) or
@@ -58,11 +85,11 @@ class ShardedChain:
                                         C.c_void_p(d_wtns) if d_wtns is not None else None,
                                         C.c_void_p(ra.ctypes.data) if ra is not None else None,
                                         C.c_void_p(sa.ctypes.data) if sa is not None else None, stream))
-        self.exchange(self.xb, self.abc)
+        self.exchange(self.recv, self.send)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_CROSS_INVERSE, stream))
-        self.exchange(self.abc, self.xb)
+        self.exchange(self.send, self.recv)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_LOCAL, stream))
-        self.exchange(self.xb, self.abc)
+        self.exchange(self.recv, self.send)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_CROSS_FORWARD, stream))
-        self.exchange(self.abc, self.xb)
+        self.exchange(self.send, self.recv)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_FINISH, stream))

@@ -67,7 +67,7 @@ def load_library():
                          "or `make -C rapidsnark-old_amd/csrc`; there is no CPU fallback" % path)
     # six streams per prover: the HIP runtime's default of 4 hardware queues aliases them and the
     # witness upload of proof k+1 then queues behind proof k (csrc/prover.hip); read at HIP init
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     try:
         # torch wheels bundle their own libamdhip64; load it FIRST so this process holds ONE HIP
         # runtime (two runtimes => the second one sees "No HIP GPUs are available").

@@ -85,7 +85,7 @@ def test_partitioned_chain_at_scale(zk, tmp_path, k, shards):
 def test_shard_step_api_with_emulated_all_to_all(zk, shards):
     """zk_shard_begin / zk_shard_step as a one-process-per-GPU job drives them (rapidsnark_old_amd.dist.
     ShardedChain), with dist.all_to_all_single played by copies between the ranks' registered buffers:
-    rank r receives chunk r of every rank's block."""
+    part r of every rank's send buffer lands in rank r's receive buffer."""
     import torch
     from rapidsnark_old_amd import lib as L
     from rapidsnark_old_amd.dist import ShardedChain
@@ -109,19 +109,18 @@ def test_shard_step_api_with_emulated_all_to_all(zk, shards):
         assert [t[0] for t in reqs] == list(range(shards))
         srcs = [t[2].clone() for t in reqs]
         for rnk, dst, _ in reqs:
-            for poly in range(3):
-                ch = dst.shape[1] // shards
-                for sidx in range(shards):
-                    dst[poly, sidx * ch:(sidx + 1) * ch] = srcs[sidx][poly, rnk * ch:(rnk + 1) * ch]
+            part = dst.numel() // shards
+            for sidx in range(shards):      # all_to_all_single: part `rnk` of rank sidx's buffer -> part sidx of mine
+                dst[sidx * part:(sidx + 1) * part] = srcs[sidx][rnk * part:(rnk + 1) * part]
         pending.clear()
 
     # drive the ranks in lock-step: each phase of every rank, then the exchange
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for ch, p in zip(chains, provers):
         L.check(p._lib.zk_shard_begin(p._h, C.c_void_p(wt.ctypes.data), None, None, None, stream))
-        ch.exchange(ch.xb, ch.abc)
+        ch.exchange(ch.recv, ch.send)
     run_all_to_all()
-    for step, (dst, src) in ((L.ZK_STEP_CROSS_INVERSE, ("abc", "xb")), (L.ZK_STEP_LOCAL, ("xb", "abc")), (L.ZK_STEP_CROSS_FORWARD, ("abc", "xb"))):
+    for step, (dst, src) in ((L.ZK_STEP_CROSS_INVERSE, ("send", "recv")), (L.ZK_STEP_LOCAL, ("recv", "send")), (L.ZK_STEP_CROSS_FORWARD, ("send", "recv"))):
         for ch, p in zip(chains, provers):
             L.check(p._lib.zk_shard_step(p._h, step, stream))
             ch.exchange(getattr(ch, dst), getattr(ch, src))

@@ -6,7 +6,7 @@ but the work (kernels, sizes, launch counts) is exactly a rank's — what is mis
 all_to_all (2 x 7/8 of a block per transform over xGMI at G = 8)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch
 import bench
 import rapidsnark_old_amd as zk
