@@ -443,14 +443,14 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         // pile up after the last one.  Measured with two proofs in flight: 2^22 39.7 -> 39.1 ms
         // (same box), 2^20 15.8 -> 13.5 ms, a shard of 8 at 2^22 12.4 -> 11.3 ms; one proof at a
         // time it is neutral from 2^20 up (2^18: 7.6 -> 8.0 ms).  ZKHIP_TAIL=0 turns them off.
-        // One follow-up stream PER MSM (five): with two (one per main stream) the tails of three MSMs
-        // queued on one stream, and on small circuits — where every kernel is latency-bound — that
-        // stream's 2.3 ms of serial merges and reductions per proof was the proof period at 2^16
-        // whatever the number of proofs in flight.  ZKHIP_TAIL=2 restores the two-stream layout.
+        // Two follow-up streams (the tails of stream 2's MSMs on one, of stream 1's on the other).  One per
+        // MSM (ZKHIP_TAIL=5) was measured neutral at every size from 2^14 to 2^22 (tools/ab_tailstreams.sh)
+        // — at most four kernels ever run concurrently in a proof's trace, whatever the number of streams —
+        // and costs three more hardware queues.
         const char *e = getenv("ZKHIP_TAIL");
-        int ntail = e ? atoi(e) : 5;
+        int ntail = e ? atoi(e) : 2;
         if (getenv("ZKHIP_SERIAL")) ntail = 0;
-        if (ntail != 0 && ntail != 2) ntail = 5;
+        if (ntail != 0 && ntail != 5) ntail = 2;
         p->tail_streams = ntail;
         if (ntail) {
             int lo_pr = 0, hi_pr = 0;
