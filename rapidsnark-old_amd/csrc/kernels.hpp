@@ -131,6 +131,17 @@ struct AccumTail {
     hipStream_t stream = nullptr;
     hipEvent_t l1_done = nullptr;
 };
+// Up to three G1 MSMs over the SAME sorted entry list in one set of launches (blockIdx.y): MSM m uses
+// points[m], writes buckets + m*bucket_stride and the workspaces + m*ws_stride.
+struct AccumBatch {
+    uint32_t n;
+    const void *points[3];
+    uint32_t idx_min[3], idx_sub[3];
+    uint64_t bucket_stride, ws_stride;
+};
+void launch_msm_accum_g1_batch(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const AccumBatch &batch, uint32_t total_buckets,
+                               uint64_t max_entries, G1Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,
+                               AccumTail tail = AccumTail());
 void launch_msm_accum_g1(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
                          G1Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,

@@ -517,12 +517,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 // Occupancy is what the compiler picks: G1 132 VGPRs (3 waves/SIMD), G2 256 + 53 AGPRs (1 wave/SIMD).
 // Forcing 4 G1 waves (128 VGPRs, 20 B scratch) or 2 G2 waves (256 VGPRs, 256 B scratch) was measured
 // slower for the whole proof.
+// blockIdx.y selects one of up to three MSMs over the SAME sorted entry list (A, B1, C share sort(w)):
+// small circuits launch them together — a level-1 launch there is latency-bound (a lane's chain of 32
+// adds, a grid that does not fill the chip) and three of them cost what one costs.
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
-                                                      const Affine<F> *points, uint32_t idx_min, uint32_t idx_sub,
-                                                      uint32_t nbuckets_total, G1Acc *out_part, uint32_t *out_key,
-                                                      uint32_t *out_flag, uint32_t nlanes, uint32_t ACC_CHUNK) {
+__global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets0, const uint32_t *offsets, const uint32_t *entries,
+                                                      AccumBatch batch, uint32_t nbuckets_total, G1Acc *out_part0, uint32_t *out_key0,
+                                                      uint32_t *out_flag0, uint32_t nlanes, uint32_t ACC_CHUNK) {
     static_assert(sizeof(F) == sizeof(Fq), "G1 only: the G2 level-1 kernel is k_msm_accum_l1_g2s");
+    const uint32_t m = blockIdx.y;
+    G1Acc *buckets = buckets0 + (uint64_t)m * batch.bucket_stride;
+    G1Acc *out_part = out_part0 + (uint64_t)m * batch.ws_stride;
+    uint32_t *out_key = out_key0 + (uint64_t)m * batch.ws_stride, *out_flag = out_flag0 + (uint64_t)m * batch.ws_stride;
+    const Affine<F> *points = reinterpret_cast<const Affine<F> *>(batch.points[m]);
+    const uint32_t idx_min = batch.idx_min[m], idx_sub = batch.idx_sub[m];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nlanes) return;
     const uint32_t E = offsets[nbuckets_total];
@@ -677,8 +685,12 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2Acc *buckets, const 
 // buckets spanning three or more chunks (top window, skewed witnesses).
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_pair(ACCMEM *buckets, const ACCMEM *part, uint32_t *key, const uint32_t *flag,
-                                                        uint32_t nlanes) {
+                                                        uint32_t nlanes, uint64_t bucket_stride, uint64_t ws_stride) {
     typedef LaneModel<F> LM;
+    buckets += (uint64_t)blockIdx.y * bucket_stride;      // blockIdx.y: MSM of a batch (see k_msm_accum_l1)
+    part += (uint64_t)blockIdx.y * ws_stride;
+    key += (uint64_t)blockIdx.y * ws_stride;
+    flag += (uint64_t)blockIdx.y * ws_stride;
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = gt / LM::LPE;
     if (t + 1 >= nlanes) return;
@@ -727,9 +739,16 @@ template <> __device__ __forceinline__ Fq2s wave_push<Fq2s>(const Fq2s &v, uint3
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_wave(ACCMEM *buckets, const ACCMEM *in_part, const uint32_t *in_key,
                                                         const uint32_t *in_flag, uint32_t nitems, ACCMEM *out_part,
-                                                        uint32_t *out_key, uint32_t *out_flag, uint32_t nwaves) {
+                                                        uint32_t *out_key, uint32_t *out_flag, uint32_t nwaves,
+                                                        uint64_t bucket_stride, uint64_t ws_stride) {
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
+    {
+        const uint64_t bo = (uint64_t)blockIdx.y * bucket_stride, wo = (uint64_t)blockIdx.y * ws_stride;   // MSM of a batch
+        buckets += bo;
+        in_part += wo; in_key += wo; in_flag += wo;
+        out_part += wo; out_key += wo; out_flag += wo;
+    }
     constexpr uint32_t LPE = LM::LPE, EPW = 64u / LPE;          // lanes per element, elements per wave
     const uint32_t lane = threadIdx.x & 63u, w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (w >= nwaves) return;                                    // wave-uniform
@@ -1037,20 +1056,21 @@ uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
 }
 
 template <class F>
-static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_t *entries, const Affine<F> *points,
-                         uint32_t idx_min, uint32_t idx_sub, uint32_t total_buckets, uint64_t max_entries,
+static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_t *entries, AccumBatch batch,
+                         uint32_t total_buckets, uint64_t max_entries,
                          ACCMEM *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
+    const uint32_t nb = batch.n ? batch.n : 1;
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
-    ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)total_buckets * sizeof(ACCMEM), s));
+    ZK_HIP(hipMemsetAsync(buckets, 0, ((size_t)(nb - 1) * batch.bucket_stride + total_buckets) * sizeof(ACCMEM), s));
     uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
         hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
-                           points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
-                           accum_chunk_for(max_entries ? max_entries : 1));
+                           reinterpret_cast<const G2Affine *>(batch.points[0]), batch.idx_min[0], batch.idx_sub[0], total_buckets, ws_part, ws_key, ws_flag,
+                           (uint32_t)lanes, accum_chunk_for(max_entries ? max_entries : 1));
     } else {
-        hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
-                           points, idx_min, idx_sub, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
+        hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256), nb), dim3(256), 0, s, buckets, offsets, entries,
+                           batch, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
                            accum_chunk_for(max_entries ? max_entries : 1));
     }
     if (ev) ZK_HIP(hipEventRecord(ev[1], s));
@@ -1060,31 +1080,47 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
         s = tail.stream;
     }
     if (lanes > 1)
-        hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256)), dim3(256), 0, s, buckets,
-                           (const ACCMEM *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes);
+        hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256), nb), dim3(256), 0, s, buckets,
+                           (const ACCMEM *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes, batch.bucket_stride, batch.ws_stride);
     uint64_t off = 0;
     while (lanes > 1) {          // a single unit has no cut runs: everything it saw was complete
         uint64_t items = 2 * lanes;
         uint64_t noff = off + items;
         const uint64_t epw = 64u / LaneModel<F>::LPE;
         const uint64_t nl = (items + epw - 1) / epw;             // waves; each emits two slots
-        hipLaunchKernelGGL(k_msm_accum_wave<F>, dim3((uint32_t)((nl + 3) / 4)), dim3(256), 0, s, buckets, ws_part + off,
-                           ws_key + off, ws_flag + off, (uint32_t)items, ws_part + noff, ws_key + noff, ws_flag + noff, (uint32_t)nl);
+        hipLaunchKernelGGL(k_msm_accum_wave<F>, dim3((uint32_t)((nl + 3) / 4), nb), dim3(256), 0, s, buckets, ws_part + off,
+                           ws_key + off, ws_flag + off, (uint32_t)items, ws_part + noff, ws_key + noff, ws_flag + noff, (uint32_t)nl,
+                           batch.bucket_stride, batch.ws_stride);
         off = noff;
         lanes = nl;
     }
     ZK_LAUNCH_OK("msm bucket accumulation");
 }
 
+static AccumBatch single(const void *points, uint32_t idx_min, uint32_t idx_sub) {
+    AccumBatch b;
+    memset(&b, 0, sizeof b);
+    b.n = 1;
+    b.points[0] = points;
+    b.idx_min[0] = idx_min;
+    b.idx_sub[0] = idx_sub;
+    return b;
+}
+
 void launch_msm_accum_g1(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G1Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G1Acc *ws_part,
                          uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
-    launch_accum<Fq>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
+    launch_accum<Fq>(buckets, offsets, entries, single(points, idx_min, idx_sub), total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
+}
+void launch_msm_accum_g1_batch(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const AccumBatch &batch, uint32_t total,
+                               uint64_t max_entries, G1Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev,
+                               AccumTail tail) {
+    launch_accum<Fq>(buckets, offsets, entries, batch, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
 void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2Acc *ws_part,
                          uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
-    launch_accum<Fq2>(buckets, offsets, entries, points, idx_min, idx_sub, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
+    launch_accum<Fq2>(buckets, offsets, entries, single(points, idx_min, idx_sub), total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
 
 template <class F>

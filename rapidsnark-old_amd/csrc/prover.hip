@@ -210,11 +210,14 @@ struct zk_prover {
         DevBuf<G1Acc> buckets_g1;    // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
         DevBuf<G2Acc> buckets_g2;
         // accumulation workspaces, one per MSM: 0 = A, 1 = B1, 2 = C, 3 = H (G1), 4 = B2 (G2)
-        DevBuf<G1Acc> scratch_g1, acc_ws_g1[4];
+        DevBuf<G1Acc> scratch_g1, acc_ws_g1_all;       // accumulation workspaces of MSM A | B1 | C (equal strides: batched launches) | H
+        G1Acc *acc_ws_g1[4] = {nullptr, nullptr, nullptr, nullptr};
+        DevBuf<uint32_t> acc_key_all, acc_flag_all;    // A | B1 | C | H | B2
+        uint32_t *acc_key[5] = {nullptr}, *acc_flag[5] = {nullptr};
+        uint64_t acc_stride = 0;
         DevBuf<G2Acc> scratch_g2, acc_ws_g2;
         DevBuf<G1XYZZ> wsum_g1;
         DevBuf<G2XYZZ> wsum_g2;
-        DevBuf<uint32_t> acc_key[5], acc_flag[5];
         hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_done = nullptr;
         hipEvent_t ev_tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -266,6 +269,7 @@ struct zk_prover {
     hipStream_t tail_pool[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int tail_streams = 0;
+    bool batch_abc = false;     // MSM A, B1, C in one set of launches (small circuits; ZKHIP_BATCH_ABC=0/1 overrides)
     hipStream_t stream_fin = nullptr;                   // joins a proof's streams and copies its window sums to the host
     hipStream_t stream_h2d = nullptr;                   // witness uploads of host-witness proofs
 
@@ -342,12 +346,16 @@ static void alloc_slot(zk_prover *p, int i) {
     q.scratch_g2.alloc(msm_reduce_scratch_points(1, pw));
     q.wsum_g2.alloc(pw.sets);
     const uint64_t slots = msm_accum_workspace_slots(q.sort_w.max_entries()), slots_h = msm_accum_workspace_slots(p->sort_h.max_entries());
-    for (int m = 0; m < 5; m++) {
-        const uint64_t sl = m == 3 ? slots_h : slots;
-        if (m < 4) q.acc_ws_g1[m].alloc(sl);
-        else q.acc_ws_g2.alloc(sl);
-        q.acc_key[m].alloc(sl);
-        q.acc_flag[m].alloc(sl);
+    q.acc_stride = slots;
+    q.acc_ws_g1_all.alloc(3 * slots + slots_h);
+    q.acc_ws_g2.alloc(slots);
+    q.acc_key_all.alloc(4 * slots + slots_h);
+    q.acc_flag_all.alloc(4 * slots + slots_h);
+    for (int m = 0; m < 5; m++) {          // A, B1, C at m*slots; H behind them; B2 last
+        const uint64_t at = m < 3 ? m * slots : (m == 3 ? 3 * slots : 3 * slots + slots_h);
+        if (m < 4) q.acc_ws_g1[m] = q.acc_ws_g1_all.p + at;
+        q.acc_key[m] = q.acc_key_all.p + at;
+        q.acc_flag[m] = q.acc_flag_all.p + at;
     }
     q.w1_bytes = (size_t)(3 * pw.sets + ph.sets) * sizeof(G1XYZZ);
     q.w2_bytes = (size_t)pw.sets * sizeof(G2XYZZ);
@@ -478,6 +486,11 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->log_shards = lg;
     }
     p->nloc = p->part ? p->sh.size() : n;
+    {
+        // below ~2^19 a proof is bound by the latencies of its kernels, not by their work
+        const char *e = getenv("ZKHIP_BATCH_ABC");
+        p->batch_abc = e ? atoi(e) != 0 : p->sv.size() < (1u << 19);
+    }
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_out, hipEventDisableTiming));
 
@@ -707,11 +720,26 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     const uint32_t tbw = c.tbw, Ww = c.Ww;
     const uint64_t ew = c.ew;
     const MsmPlan pw = c.pw;
-    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4].p, q.acc_flag[4].p, s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
+    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
     if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, p->tail[4]);
-    launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0].p, q.acc_key[0].p, q.acc_flag[0].p, s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
+    if (p->batch_abc) {
+        // small circuits: MSM A, B1 and C (same scalars, same sorted entries) in ONE set of launches —
+        // level-1 accumulation, merges and bucket reduction each cost what one MSM's cost
+        AccumBatch b;
+        memset(&b, 0, sizeof b);
+        b.n = 3;
+        b.points[0] = p->ptsA.p; b.points[1] = p->ptsB1.p; b.points[2] = p->ptsC.p;
+        b.idx_min[2] = b.idx_sub[2] = p->c_idx_min;
+        b.bucket_stride = tbw;
+        b.ws_stride = q.acc_stride;
+        launch_msm_accum_g1_batch(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, b, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
+        if (tm) for (int e : {13, 14, 15, 16}) HIP_TRY(hipEventRecord(q.ev[e], s2));      // (B1 and C have no launch of their own)
+        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 3, pw, c.after(0, s2));
+        HIP_TRY(hipEventRecord(q.ev_join, s2));
+    } else {
+    launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
     if (tails) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, p->tail[0]);
-    launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1].p, q.acc_key[1].p, q.acc_flag[1].p, s2, tm ? &q.ev[13] : nullptr, c.tail_of(1));
+    launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1], q.acc_key[1], q.acc_flag[1], s2, tm ? &q.ev[13] : nullptr, c.tail_of(1));
     if (tails) {
         launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, p->tail[1]);
     } else {
@@ -720,6 +748,7 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
         launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 2, pw, s2);
     }
     HIP_TRY(hipEventRecord(q.ev_join, s2));
+    }
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
     // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96) — on the rows this prover holds
@@ -794,15 +823,17 @@ void phase_back(zk_prover *p) {
     p->sort_h.run(p->h.p + (p->part ? 0 : p->sh.lo), s);
     c.mark(3);
     // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
-    launch_msm_accum_g1(c.bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, c.tbh, c.eh, q.acc_ws_g1[3].p, q.acc_key[3].p, q.acc_flag[3].p, s, c.tm ? &q.ev[17] : nullptr, c.tail_of(3));
+    launch_msm_accum_g1(c.bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, c.tbh, c.eh, q.acc_ws_g1[3], q.acc_key[3], q.acc_flag[3], s, c.tm ? &q.ev[17] : nullptr, c.tail_of(3));
     c.mark(4);
     launch_msm_reduce_g1(q.wsum_g1.p + 3 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, c.pw), c.bH, 1, p->sort_h.plan, c.after(3, s));
     // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w).  (Moving it to
     // stream2 was measured slower at every shard count; so was raising stream 1's priority for
     // anything but the two-in-flight throughput of 4-8 shards.)
+    if (!p->batch_abc) {
     HIP_TRY(hipStreamWaitEvent(s, q.ev_sortw, 0));
-    launch_msm_accum_g1(c.bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, c.tbw, c.ew, q.acc_ws_g1[2].p, q.acc_key[2].p, q.acc_flag[2].p, s, c.tm ? &q.ev[15] : nullptr, c.tail_of(2));
+    launch_msm_accum_g1(c.bC, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsC.p, p->c_idx_min, p->c_idx_min, c.tbw, c.ew, q.acc_ws_g1[2], q.acc_key[2], q.acc_flag[2], s, c.tm ? &q.ev[15] : nullptr, c.tail_of(2));
     launch_msm_reduce_g1(q.wsum_g1.p + 2 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(2, c.pw), c.bC, 1, c.pw, c.after(2, s));
+    }
     c.mark(5);
     HIP_TRY(hipEventRecord(q.ev_main, s));
 
