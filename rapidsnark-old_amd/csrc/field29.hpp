@@ -52,6 +52,18 @@ struct Fp29 {
     static constexpr const int32_t (&K_IN)[9] = PR::K_IN;
     static constexpr const int32_t (&K_OUT)[9] = PR::K_OUT;
 
+    // Modulus limb for the reduction MADs.  On the device the value is pinned in an SGPR through an (empty,
+    // CSE-able) asm: left to itself the compiler parks p[1..8] in 8 VGPRs that it re-loads from a constant
+    // table inside every loop iteration of the bucket kernels (two global_load_dwordx4 + a wait per point).
+    ZK_HD static int32_t PS(int k) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_SGPR_MODULUS)
+        int32_t r;
+        asm("" : "=s"(r) : "0"(__builtin_amdgcn_readfirstlane(P[k])));
+        return r;
+#else
+        return P[k];
+#endif
+    }
     ZK_HD static Fq29 zero() {
         Fq29 r;
 #pragma unroll
@@ -138,9 +150,9 @@ struct Fp29 {
 #pragma unroll
             for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P[k - i];
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * PS(k - i);
             m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
-            acc += (int64_t)m[k] * P[0];
+            acc += (int64_t)m[k] * PS(0);
             acc >>= 29;          // exact: the low 29 bits are zero now
         }
 #pragma unroll
@@ -148,7 +160,7 @@ struct Fp29 {
 #pragma unroll
             for (int i = k - 8; i <= 8; i++) acc += (int64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * P[k - i];
+            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * PS(k - i);
             r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
             acc >>= 29;
         }
@@ -169,9 +181,9 @@ struct Fp29 {
             for (int i = 0; 2 * i < k; i++) acc += (int64_t)a2[i] * a.l[k - i];
             if ((k & 1) == 0) acc += (int64_t)a.l[k >> 1] * a.l[k >> 1];
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P[k - i];
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * PS(k - i);
             m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
-            acc += (int64_t)m[k] * P[0];
+            acc += (int64_t)m[k] * PS(0);
             acc >>= 29;
         }
 #pragma unroll
@@ -180,7 +192,7 @@ struct Fp29 {
             for (int i = k - 8; 2 * i < k; i++) acc += (int64_t)a2[i] * a.l[k - i];
             if ((k & 1) == 0) acc += (int64_t)a.l[k >> 1] * a.l[k >> 1];
 #pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * P[k - i];
+            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * PS(k - i);
             r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
             acc >>= 29;
         }
@@ -203,9 +215,9 @@ struct Fp29 {
                 acc += (int64_t)c.l[i] * d.l[k - i];
             }
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P[k - i];
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * PS(k - i);
             m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
-            acc += (int64_t)m[k] * P[0];
+            acc += (int64_t)m[k] * PS(0);
             acc >>= 29;
         }
 #pragma unroll
@@ -216,7 +228,7 @@ struct Fp29 {
                 acc += (int64_t)c.l[i] * d.l[k - i];
             }
 #pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * P[k - i];
+            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * PS(k - i);
             r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
             acc >>= 29;
         }

@@ -138,6 +138,7 @@ struct AccumBatch {
     const void *points[3];
     uint32_t idx_min[3], idx_sub[3];
     uint64_t bucket_stride, ws_stride;
+    uint32_t gather_mask;          // 0xffffffff; anything else is a measurement probe (results are wrong)
 };
 void launch_msm_accum_g1_batch(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const AccumBatch &batch, uint32_t total_buckets,
                                uint64_t max_entries, G1Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev = nullptr,

@@ -505,10 +505,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 //     edge to its TAIL slot (at most one of each), tagged with its bucket and STARTS/ENDS flags;
 //   * the slot list (2 per lane, still bucket-sorted) is reduced by wave-parallel segmented scans over
 //     XYZZ partials (k_msm_accum_wave), shrinking 32x (G2: 16x) per level until one wave is left.
-// Work per lane is constant, so the kernel time is flat in the scalar distribution.  The chunk
-// is 128 entries, halved (to 32) for small or sharded MSMs so every SIMD still gets ~3 waves.
-#define ACC_CHUNK_MAX 128u  // affine points per lane, level 1 (halved until >= ~3 waves/SIMD of lanes exist)
-#define ACC_CHUNK_MIN 32u
+// Work per lane is constant, so the kernel time is flat in the scalar distribution.  Because it is constant,
+// the grid runs in lock-step "rounds" of as many workgroups as fit on the chip at once (G1: 3 waves/SIMD =
+// 768 workgroups, G2: 2 waves/SIMD = 512), and a last round that is only partly full costs a whole round:
+// at 2^22 a fixed chunk of 128 gave 1664 workgroups = 2.17 rounds, i.e. the kernel ran at 72% of its own
+// rate.  So the host launches a WHOLE number of rounds of lanes (accum_lanes_for) and the chunk is whatever
+// divides the entries evenly among them (32..160 entries; below 32 fewer lanes are launched instead).
+#define ACC_CHUNK_MAX 160u  // affine points per lane, level 1: more than this and another round of lanes is launched
+#define ACC_CHUNK_MIN 32u   // fewer than this and fewer lanes are launched (small or sharded MSMs)
+// Every lane takes the same share of the E entries actually present (E <= max_entries is known on the device
+// only): the host fixes the number of lanes, the chunk follows.
+__device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes, uint32_t chunk_min) {
+    const uint32_t c = (uint32_t)(((uint64_t)E + nlanes - 1) / nlanes);
+    return c < chunk_min ? chunk_min : c;
+}
 #define ACC_CHUNK_N 32u     // slots per unit at levels >= 2 used to SIZE the workspace (a G2 wave takes 32, a G1 wave 64)
 #define SLOT_EMPTY 0xffffffffu
 #define FLAG_STARTS 1u
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets0, const uint32_t *offsets, const uint32_t *entries,
                                                       AccumBatch batch, uint32_t nbuckets_total, G1Acc *out_part0, uint32_t *out_key0,
-                                                      uint32_t *out_flag0, uint32_t nlanes, uint32_t ACC_CHUNK) {
+                                                      uint32_t *out_flag0, uint32_t nlanes, uint32_t chunk_min) {
     static_assert(sizeof(F) == sizeof(Fq), "G1 only: the G2 level-1 kernel is k_msm_accum_l1_g2s");
     const uint32_t m = blockIdx.y;
     G1Acc *buckets = buckets0 + (uint64_t)m * batch.bucket_stride;
@@ -534,6 +544,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets0, const uin
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nlanes) return;
     const uint32_t E = offsets[nbuckets_total];
+    const uint32_t ACC_CHUNK = accum_chunk_dev(E, nlanes, chunk_min);
     const uint64_t lo64 = (uint64_t)t * ACC_CHUNK;
     uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
     if (lo64 < E) {
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets0, const uin
             uint32_t idx = ent & 0x7fffffffu;
             nextNeg = (ent >> 31) != 0;
             nextSkip = idx < idx_min;
-            const Affine<F> *src = points + (nextSkip ? 0 : idx - idx_sub);
+            const Affine<F> *src = points + (nextSkip ? 0 : (idx - idx_sub) & batch.gather_mask);
             nextP.x = load_el(&src->x);
             nextP.y = load_el(&src->y);
         };
@@ -606,11 +617,12 @@ __global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets0, const uin
 __global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                           const G2Affine *points, uint32_t idx_min, uint32_t idx_sub,
                                                           uint32_t nbuckets_total, G2Acc *out_part, uint32_t *out_key,
-                                                          uint32_t *out_flag, uint32_t nlanes, uint32_t ACC_CHUNK) {
+                                                          uint32_t *out_flag, uint32_t nlanes, uint32_t chunk_min) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = gt >> 1, comp = gt & 1u;          // chunk, component (blockDim is even: comp == threadIdx.x & 1)
     if (t >= nlanes) return;
     const uint32_t E = offsets[nbuckets_total];
+    const uint32_t ACC_CHUNK = accum_chunk_dev(E, nlanes, chunk_min);
     const uint64_t lo64 = (uint64_t)t * ACC_CHUNK;
     uint32_t hkey = SLOT_EMPTY, tkey = SLOT_EMPTY, hflag = 0, tflag = 0;
     auto store_comp = [&](G2Acc *dst, const XYZZ<Fq2s> &v) { LaneModel<Fq2>::store(dst, v); };   // this lane's component (comp == threadIdx.x & 1)
@@ -1033,18 +1045,45 @@ void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, M
 void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq2>(table, tmp, pref, n, p, s); }
 
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
-static inline uint32_t accum_chunk_for(uint64_t max_entries) {
-    uint32_t chunk = ACC_CHUNK_MAX;
+static inline uint32_t accum_chunk_min() {
     static const uint32_t cmin = [] { const char *e = getenv("ZKHIP_ACC_CHUNK_MIN"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MIN; return v < 4u ? 4u : v; }();
-    while (chunk > cmin && max_entries / chunk < 3u * 1024u * 64u) chunk >>= 1;   // 256 CUs x 4 SIMDs x 3 waves
-    return chunk;
+    return cmin;
 }
-static inline uint64_t accum_l1_lanes(uint64_t max_entries) {
-    uint32_t chunk = accum_chunk_for(max_entries);
-    return (max_entries + chunk - 1) / chunk;
+static inline uint32_t accum_chunk_max() {
+    static const uint32_t cmax = [] { const char *e = getenv("ZKHIP_ACC_CHUNK_MAX"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MAX; return v < 8u ? 8u : v; }();
+    return cmax;
+}
+// chunks one round holds: what the occupancy calculator says fits on the device at once (per MSM of a batch)
+template <class F>
+static uint64_t accum_round_lanes(uint32_t n_msm) {
+    static const uint64_t threads = [] {
+        int dev = 0, cus = 256, wgs = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) {
+            if constexpr (sizeof(F) == sizeof(Fq2)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1_g2s, 256, 0);
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1<F>, 256, 0);
+        }
+        if (e != hipSuccess || wgs < 1) { (void)hipGetLastError(); wgs = sizeof(F) == sizeof(Fq2) ? 2 : 3; }
+        if (const char *o = getenv("ZKHIP_ACC_ROUND_WGS")) wgs = atoi(o) > 0 ? atoi(o) : wgs;   // workgroups per CU (probe)
+        return (uint64_t)wgs * 256u * (uint64_t)cus;
+    }();
+    uint64_t lanes = threads / LaneModel<F>::LPE / (n_msm ? n_msm : 1);
+    return lanes ? lanes : 1;
+}
+template <class F>
+static inline uint64_t accum_lanes_for(uint64_t max_entries, uint32_t n_msm) {
+    if (!max_entries) max_entries = 1;
+    const uint64_t R = accum_round_lanes<F>(n_msm), cmin = accum_chunk_min(), cmax = accum_chunk_max();
+    if (max_entries <= R * cmin) return (max_entries + cmin - 1) / cmin;       // one partial round of minimum chunks
+    const uint64_t rounds = (max_entries + R * cmax - 1) / (R * cmax);
+    return rounds * R;
 }
 uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
-    uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
+    // one size for whichever MSM uses the workspace: single G1, one of a G1 batch, G2
+    uint64_t lanes = accum_lanes_for<Fq>(max_entries, 1);
+    for (uint32_t nb = 2; nb <= 3; nb++) lanes = std::max(lanes, accum_lanes_for<Fq>(max_entries, nb));
+    lanes = std::max(lanes, accum_lanes_for<Fq2>(max_entries, 1));
     uint64_t total = 0;
     for (;;) {
         uint64_t slots = 2 * lanes;
@@ -1062,16 +1101,15 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
     const uint32_t nb = batch.n ? batch.n : 1;
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
     ZK_HIP(hipMemsetAsync(buckets, 0, ((size_t)(nb - 1) * batch.bucket_stride + total_buckets) * sizeof(ACCMEM), s));
-    uint64_t lanes = accum_l1_lanes(max_entries ? max_entries : 1);
+    uint64_t lanes = accum_lanes_for<F>(max_entries, nb);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
         hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
                            reinterpret_cast<const G2Affine *>(batch.points[0]), batch.idx_min[0], batch.idx_sub[0], total_buckets, ws_part, ws_key, ws_flag,
-                           (uint32_t)lanes, accum_chunk_for(max_entries ? max_entries : 1));
+                           (uint32_t)lanes, accum_chunk_min());
     } else {
         hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256), nb), dim3(256), 0, s, buckets, offsets, entries,
-                           batch, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes,
-                           accum_chunk_for(max_entries ? max_entries : 1));
+                           batch, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes, accum_chunk_min());
     }
     if (ev) ZK_HIP(hipEventRecord(ev[1], s));
     if (tail.stream && tail.stream != s) {            // partial merges continue on the caller's follow-up stream
@@ -1097,10 +1135,15 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
     ZK_LAUNCH_OK("msm bucket accumulation");
 }
 
+static uint32_t gather_mask_env() {      // ZKHIP_GATHER_MASK (probe only, WRONG results): confine the G1 table gathers to the low rows
+    static const uint32_t m = [] { const char *e = getenv("ZKHIP_GATHER_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
+    return m;
+}
 static AccumBatch single(const void *points, uint32_t idx_min, uint32_t idx_sub) {
     AccumBatch b;
     memset(&b, 0, sizeof b);
     b.n = 1;
+    b.gather_mask = gather_mask_env();
     b.points[0] = points;
     b.idx_min[0] = idx_min;
     b.idx_sub[0] = idx_sub;
@@ -1115,7 +1158,9 @@ void launch_msm_accum_g1(G1Acc *buckets, const uint32_t *offsets, const uint32_t
 void launch_msm_accum_g1_batch(G1Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const AccumBatch &batch, uint32_t total,
                                uint64_t max_entries, G1Acc *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev,
                                AccumTail tail) {
-    launch_accum<Fq>(buckets, offsets, entries, batch, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
+    AccumBatch b = batch;
+    b.gather_mask = gather_mask_env();
+    launch_accum<Fq>(buckets, offsets, entries, b, total, max_entries, ws_part, ws_key, ws_flag, s, ev, tail);
 }
 void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries, const G2Affine *points,
                          uint32_t idx_min, uint32_t idx_sub, uint32_t total, uint64_t max_entries, G2Acc *ws_part,
