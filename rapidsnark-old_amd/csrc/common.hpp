@@ -26,6 +26,12 @@ struct HostTail {
                                const uint8_t pi_b[128], const uint8_t pi_c[64],
                                const uint8_t r32[32], const uint8_t s32[32],
                                uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
+    // the same from the GPU's window sums (XYZZ; G1: A, B1, C [Ww each] then H [Wh]; G2: B2 [Ww]); r32 / s32 NULL = drawn
+    // like the reference's randombytes_buf(31 bytes).  Returns nonzero when the random source fails.
+    static int finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                                   const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                                   const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t Wh, uint32_t ch,
+                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
     // canonical base-10 of a 32-byte LE integer
     static std::string to_dec(const uint8_t le32[32]);
     // de-Montgomery an Fq element and print base-10 (E.f1.toString, src/groth16.cpp:274)

@@ -8,6 +8,9 @@
 #include <string.h>
 #include <stdio.h>
 #include <sys/random.h>
+#include <list>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -25,16 +28,20 @@ typedef XYZZ<Fq2h> G2P;
 
 static_assert(sizeof(G1A) == 64 && sizeof(G2A) == 128 && sizeof(G1P) == 128 && sizeof(G2P) == 256, "layout");
 
-template <class PT, class AT>
-static void combine_windows(const uint8_t *w, uint32_t W, uint32_t c, uint8_t *out) {
+template <class PT>
+static PT horner(const uint8_t *w, uint32_t W, uint32_t c) {
     PT acc = PT::inf();
     for (int i = (int)W - 1; i >= 0; i--) {
-        for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
+        if (!acc.is_inf()) for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
         PT s;
         memcpy(&s, w + (size_t)i * sizeof(PT), sizeof(PT));
         add(acc, s);
     }
-    AT a = to_affine(acc);
+    return acc;
+}
+template <class PT, class AT>
+static void combine_windows(const uint8_t *w, uint32_t W, uint32_t c, uint8_t *out) {
+    AT a = to_affine(horner<PT>(w, W, c));
     memcpy(out, &a, sizeof(AT));
 }
 void HostTail::combine_windows_g1(const uint8_t *w, uint32_t W, uint32_t c, uint8_t out[64]) {
@@ -64,22 +71,160 @@ static AT load(const uint8_t *b) {
     return a;
 }
 
-void HostTail::final_assembly(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
-                              const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
-                              const uint8_t pih_b[64], const uint8_t pi_a_b[64], const uint8_t pib1_b[64],
-                              const uint8_t pi_b_b[128], const uint8_t pi_c_b[64],
-                              const uint8_t r32[32], const uint8_t s32[32],
-                              uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
+// ---- scalar multiplications of the final assembly -------------------------------------------------
+// The reference's tail (groth16.cpp:222-246) is six 256-bit double-and-add multiplications; done that
+// way they cost 0.84 ms of host time per proof here — more than the whole GPU side of a 2^14 circuit.
+// Four of the six multiply the key's delta (r*delta1, s*delta1, rs*delta1, s*delta2): fixed bases, so a
+// table of m * 16^j * delta (m = 1..8, j = 0..64, affine) turns each into <= 65 mixed additions.  The
+// other two (s*pi_a, r*pi_b1) are summed anyway: one joint signed-window pass shares their doublings.
+
+// k = sum_j d[j] * 16^j with d[j] in [-8, 7] (j < 64) and d[64] in {0, 1}
+static void recode16(const u32 k[8], int8_t d[65]) {
+    int carry = 0;
+    for (int j = 0; j < 64; j++) {
+        int v = (int)((k[j >> 3] >> ((j & 7) * 4)) & 15u) + carry;
+        carry = v >= 8;
+        d[j] = (int8_t)(carry ? v - 16 : v);
+    }
+    d[64] = (int8_t)carry;
+}
+
+template <class F>
+static Affine<F> neg_affine(const Affine<F> &a) { return Affine<F>{a.x, F::neg(a.y)}; }
+
+template <class F>
+struct FixedBase {
+    typedef XYZZ<F> PT;
+    typedef Affine<F> AT;
+    std::vector<AT> t;          // t[j*8 + m-1] = m * 16^j * base; empty = no table (use the generic multiplication)
+    bool build(const AT &base) {
+        if (base.is_inf()) return false;
+        std::vector<PT> proj(65 * 8);
+        PT b = PT::from_affine(base);
+        for (int j = 0; j < 65; j++) {
+            PT m = b;
+            proj[j * 8] = m;
+            for (int i = 1; i < 8; i++) { add(m, b); proj[j * 8 + i] = m; }
+            b = dbl(m);                                    // 16 * (16^j base) = 2 * (8 * 16^j base)
+        }
+        // one inversion for all of them: prefix products of u_i = zz_i * zzz_i
+        const size_t n = proj.size();
+        std::vector<F> u(n), pre(n);
+        F run = F::one();
+        for (size_t i = 0; i < n; i++) {
+            if (proj[i].is_inf()) return false;            // base of small order: not a key this table is for
+            u[i] = F::mul(proj[i].zz, proj[i].zzz);
+            pre[i] = run;
+            run = F::mul(run, u[i]);
+        }
+        if (run.is_zero()) return false;
+        F inv = F::inv(run);
+        t.resize(n);
+        for (size_t i = n; i-- > 0;) {
+            F ui = F::mul(inv, pre[i]);                    // 1 / u_i
+            inv = F::mul(inv, u[i]);
+            t[i] = AT{F::mul(proj[i].x, F::mul(ui, proj[i].zzz)), F::mul(proj[i].y, F::mul(ui, proj[i].zz))};
+        }
+        return true;
+    }
+    PT mul(const u32 k[8]) const {
+        int8_t d[65];
+        recode16(k, d);
+        PT acc = PT::inf();
+        for (int j = 0; j < 65; j++) {
+            if (d[j] > 0) madd(acc, t[j * 8 + d[j] - 1]);
+            else if (d[j] < 0) madd(acc, neg_affine(t[j * 8 - d[j] - 1]));
+        }
+        return acc;
+    }
+};
+
+// kp*P + kq*Q, one pass: 4 doublings + <= 2 additions per radix-16 digit
+template <class F>
+static XYZZ<F> joint_mul(const XYZZ<F> &P, const u32 kp[8], const XYZZ<F> &Q, const u32 kq[8]) {
+    typedef XYZZ<F> PT;
+    PT tp[8], tq[8];
+    tp[0] = P;
+    tq[0] = Q;
+    for (int i = 1; i < 8; i++) {
+        tp[i] = tp[i - 1]; add(tp[i], P);
+        tq[i] = tq[i - 1]; add(tq[i], Q);
+    }
+    int8_t dp[65], dq[65];
+    recode16(kp, dp);
+    recode16(kq, dq);
+    PT acc = PT::inf();
+    for (int j = 64; j >= 0; j--) {
+        if (!acc.is_inf()) for (int k = 0; k < 4; k++) acc = dbl(acc);
+        if (dp[j] > 0) add(acc, tp[dp[j] - 1]); else if (dp[j] < 0) add(acc, neg(tp[-dp[j] - 1]));
+        if (dq[j] > 0) add(acc, tq[dq[j] - 1]); else if (dq[j] < 0) add(acc, neg(tq[-dq[j] - 1]));
+    }
+    return acc;
+}
+
+// Tables of the last few keys seen (a server holds a handful of circuits; zk_assemble has no handle to keep
+// them in).  Built on first use: 65*8 additions per group, about 1.5 ms, then 0.3 ms less per proof.
+struct DeltaTables {
+    uint8_t key[64 + 128];
+    FixedBase<Fq64> d1;
+    FixedBase<Fq2h> d2;
+};
+static std::shared_ptr<const DeltaTables> delta_tables(const uint8_t vk_delta1[64], const uint8_t vk_delta2[128]) {
+    static std::mutex m;
+    static std::list<std::shared_ptr<const DeltaTables>> lru;
+    uint8_t key[192];
+    memcpy(key, vk_delta1, 64);
+    memcpy(key + 64, vk_delta2, 128);
+    {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto it = lru.begin(); it != lru.end(); ++it)
+            if (!memcmp((*it)->key, key, 192)) {
+                auto hit = *it;
+                lru.erase(it);
+                lru.push_front(hit);
+                return hit;
+            }
+    }
+    auto t = std::make_shared<DeltaTables>();          // built outside the lock: two threads may build the same key once
+    memcpy(t->key, key, 192);
+    t->d1.build(load<G1A>(vk_delta1));
+    t->d2.build(load<G2A>(vk_delta2));
+    std::lock_guard<std::mutex> lk(m);
+    lru.push_front(t);
+    if (lru.size() > 16) lru.pop_back();
+    return t;
+}
+
+// A, B, C -> affine with ONE field inversion (the G2 one goes through the norm of zz*zzz)
+static void three_to_affine(const G1P &a, const G2P &b, const G1P &c, G1A &A, G2A &B, G1A &C) {
+    if (a.is_inf() || b.is_inf() || c.is_inf()) {       // never for a real proof; keep the encoding rules in one place
+        A = to_affine(a);
+        B = to_affine(b);
+        C = to_affine(c);
+        return;
+    }
+    const Fq64 ta = Fq64::mul(a.zz, a.zzz), tc = Fq64::mul(c.zz, c.zzz);
+    const Fq2h tb = Fq2h::mul(b.zz, b.zzz);
+    const Fq64 nb = Fq64::add(Fq64::sqr(tb.a), Fq64::sqr(tb.b));
+    const Fq64 tac = Fq64::mul(ta, tc);
+    const Fq64 inv = Fq64::inv(Fq64::mul(tac, nb));
+    const Fq64 inb = Fq64::mul(inv, tac);                      // 1 / norm(tb)
+    const Fq64 iac = Fq64::mul(inv, nb);                       // 1 / (ta tc)
+    const Fq64 ia = Fq64::mul(iac, tc), ic = Fq64::mul(iac, ta);
+    const Fq2h ib{Fq64::mul(tb.a, inb), Fq64::neg(Fq64::mul(tb.b, inb))};
+    A = G1A{Fq64::mul(a.x, Fq64::mul(ia, a.zzz)), Fq64::mul(a.y, Fq64::mul(ia, a.zz))};
+    C = G1A{Fq64::mul(c.x, Fq64::mul(ic, c.zzz)), Fq64::mul(c.y, Fq64::mul(ic, c.zz))};
+    B = G2A{Fq2h::mul(b.x, Fq2h::mul(ib, b.zzz)), Fq2h::mul(b.y, Fq2h::mul(ib, b.zz))};
+}
+
+static void assemble_core(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                          const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                          const G1P &pih, G1P pi_a, G1P pib1, G2P pi_b, G1P pi_c,
+                          const uint8_t r32[32], const uint8_t s32[32],
+                          uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
     u32 r[8], s[8], rs[8];
     memcpy(r, r32, 32);
     memcpy(s, s32, 32);
-    G1P pi_a = G1P::from_affine(load<G1A>(pi_a_b));
-    G1P pib1 = G1P::from_affine(load<G1A>(pib1_b));
-    G2P pi_b = G2P::from_affine(load<G2A>(pi_b_b));
-    G1P pi_c = G1P::from_affine(load<G1A>(pi_c_b));
-    G1P pih = G1P::from_affine(load<G1A>(pih_b));
-    G1P delta1 = G1P::from_affine(load<G1A>(vk_delta1));
-    G2P delta2 = G2P::from_affine(load<G2A>(vk_delta2));
 
     // rs = toMontgomery(mul(r, s)) = r*s mod r_BN in standard form (:242-243)
     Fr64 fr, fs;
@@ -88,41 +233,92 @@ void HostTail::final_assembly(const uint8_t vk_alpha1[64], const uint8_t vk_beta
     Fr64 frs = Fr64::to_mont(Fr64::mul(fr, fs));
     memcpy(rs, frs.v, 32);
 
-    // The six 256-bit scalar multiplications dominate this tail (~0.2 ms each in G1, ~0.55 ms in
-    // G2 on one core).  Four are independent of the MSM results, two more depend only on A / B1:
-    // two short waves of host threads instead of the reference's serial chain (:222-246).
-    G1P r_delta1, s_delta1, rs_delta1, s_A, r_B1;
+    const std::shared_ptr<const DeltaTables> tb = delta_tables(vk_delta1, vk_delta2);
+    G1P r_delta1, s_delta1, rs_delta1;
     G2P s_delta2;
-    {
-        std::thread t1([&] { r_delta1 = scalar_mul(delta1, r); });
-        std::thread t2([&] { s_delta1 = scalar_mul(delta1, s); });
-        std::thread t3([&] { rs_delta1 = scalar_mul(delta1, rs); });
-        s_delta2 = scalar_mul(delta2, s);
-        t1.join();
-        t2.join();
-        t3.join();
+    if (!tb->d1.t.empty()) {
+        r_delta1 = tb->d1.mul(r);
+        s_delta1 = tb->d1.mul(s);
+        rs_delta1 = tb->d1.mul(rs);
+    } else {
+        const G1P delta1 = G1P::from_affine(load<G1A>(vk_delta1));
+        r_delta1 = scalar_mul(delta1, r);
+        s_delta1 = scalar_mul(delta1, s);
+        rs_delta1 = scalar_mul(delta1, rs);
     }
+    s_delta2 = !tb->d2.t.empty() ? tb->d2.mul(s) : scalar_mul(G2P::from_affine(load<G2A>(vk_delta2)), s);
+
     madd(pi_a, load<G1A>(vk_alpha1));                       // groth16.cpp:222
     add(pi_a, r_delta1);                                    // :223-224
     madd(pi_b, load<G2A>(vk_beta2));                        // :226
     add(pi_b, s_delta2);                                    // :227-228
     madd(pib1, load<G1A>(vk_beta1));                        // :230
     add(pib1, s_delta1);                                    // :231-232
-    {
-        std::thread t1([&] { s_A = scalar_mul(pi_a, s); });
-        r_B1 = scalar_mul(pib1, r);
-        t1.join();
-    }
     add(pi_c, pih);                                         // :234
-    add(pi_c, s_A);                                         // :236-237
-    add(pi_c, r_B1);                                        // :239-240
+    add(pi_c, joint_mul(pi_a, s, pib1, r));                 // :236-240   s*pi_a + r*pi_b1
     add(pi_c, neg(rs_delta1));                              // :245-246
-    G1A A = to_affine(pi_a);                                // :249-251
-    G2A B = to_affine(pi_b);
-    G1A C = to_affine(pi_c);
+    G1A A, C;                                               // :249-251
+    G2A B;
+    three_to_affine(pi_a, pi_b, pi_c, A, B, C);
     memcpy(outA, &A, 64);
     memcpy(outB, &B, 128);
     memcpy(outC, &C, 64);
+}
+
+void HostTail::final_assembly(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                              const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                              const uint8_t pih_b[64], const uint8_t pi_a_b[64], const uint8_t pib1_b[64],
+                              const uint8_t pi_b_b[128], const uint8_t pi_c_b[64],
+                              const uint8_t r32[32], const uint8_t s32[32],
+                              uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
+    assemble_core(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, G1P::from_affine(load<G1A>(pih_b)),
+                  G1P::from_affine(load<G1A>(pi_a_b)), G1P::from_affine(load<G1A>(pib1_b)), G2P::from_affine(load<G2A>(pi_b_b)),
+                  G1P::from_affine(load<G1A>(pi_c_b)), r32, s32, outA, outB, outC);
+}
+
+static int draw31(uint8_t out[32]) {
+    // src/groth16.cpp:213-217: zero, then 31 random bytes into the low bytes
+    memset(out, 0, 32);
+    size_t got = 0;
+    while (got < 31) {
+        ssize_t k = getrandom(out + got, 31 - got, 0);
+        if (k < 0) return -1;
+        got += (size_t)k;
+    }
+    return 0;
+}
+
+// The whole tail of an unsharded proof straight from the window sums the GPU wrote (XYZZ, device layout):
+// no detour through the affine zk_msm_sums record (five inversions) that sharded provers exchange.
+int HostTail::finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                                  const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                                  const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t Wh, uint32_t ch,
+                                  const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
+    uint8_t r[32], s[32];
+    if (r32) memcpy(r, r32, 32); else if (draw31(r)) return 1;
+    if (s32) memcpy(s, s32, 32); else if (draw31(s)) return 1;
+    const size_t P1 = sizeof(G1P);
+    G1P a, b1, c, h;
+    G2P b2;
+    if (Ww > 1 || Wh > 1) {            // plain tables: five Horner chains of W*c doublings, one host thread each
+        std::thread t1([&] { a = horner<G1P>(w1, Ww, cw); });
+        std::thread t2([&] { b1 = horner<G1P>(w1 + (size_t)Ww * P1, Ww, cw); });
+        std::thread t3([&] { c = horner<G1P>(w1 + (size_t)2 * Ww * P1, Ww, cw); });
+        std::thread t4([&] { h = horner<G1P>(w1 + (size_t)3 * Ww * P1, Wh, ch); });
+        b2 = horner<G2P>(w2, Ww, cw);
+        t1.join();
+        t2.join();
+        t3.join();
+        t4.join();
+    } else {
+        a = horner<G1P>(w1, Ww, cw);
+        b1 = horner<G1P>(w1 + (size_t)Ww * P1, Ww, cw);
+        c = horner<G1P>(w1 + (size_t)2 * Ww * P1, Ww, cw);
+        h = horner<G1P>(w1 + (size_t)3 * Ww * P1, Wh, ch);
+        b2 = horner<G2P>(w2, Ww, cw);
+    }
+    assemble_core(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, h, a, b1, b2, c, r, s, outA, outB, outC);
+    return 0;
 }
 
 std::string HostTail::to_dec(const uint8_t le32[32]) {
@@ -199,17 +395,6 @@ int zk_g2_mul(uint8_t out[128], const uint8_t p[128], const uint8_t k[32]) {
     return 0;
 }
 
-static int draw31(uint8_t out[32]) {
-    // src/groth16.cpp:213-217: zero, then 31 random bytes into the low bytes
-    memset(out, 0, 32);
-    size_t got = 0;
-    while (got < 31) {
-        ssize_t k = getrandom(out + got, 31 - got, 0);
-        if (k < 0) return -1;
-        got += (size_t)k;
-    }
-    return 0;
-}
 
 int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta2, const void *vk_delta1,
                 const void *vk_delta2, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32,
@@ -227,8 +412,8 @@ int zk_assemble(const void *vk_alpha1, const void *vk_beta1, const void *vk_beta
         zk::HostTail::add_affine_g1(t.pi_c, parts[i].pi_c);
     }
     uint8_t r[32], s[32];
-    if (r32) memcpy(r, r32, 32); else if (draw31(r)) { zk::set_error("getrandom failed"); return 1; }
-    if (s32) memcpy(s, s32, 32); else if (draw31(s)) { zk::set_error("getrandom failed"); return 1; }
+    if (r32) memcpy(r, r32, 32); else if (zk::draw31(r)) { zk::set_error("getrandom failed"); return 1; }
+    if (s32) memcpy(s, s32, 32); else if (zk::draw31(s)) { zk::set_error("getrandom failed"); return 1; }
     zk::HostTail::final_assembly((const uint8_t *)vk_alpha1, (const uint8_t *)vk_beta1, (const uint8_t *)vk_beta2,
                                  (const uint8_t *)vk_delta1, (const uint8_t *)vk_delta2, t.pih, t.pi_a, t.pib1, t.pi_b,
                                  t.pi_c, r, s, out->A, out->B, out->C);

@@ -249,6 +249,24 @@ struct zk_prover {
     };
     ProofSlot slot[ZK_MAX_IN_FLIGHT];
     uint32_t next_submit = 0, next_collect = 0, in_flight = 0;
+    // Small circuits: a proof is ~60 launches of kernels that each fill a tenth of the chip and wait on a
+    // serial chain of point additions, so throughput comes from running SEVERAL PROOFS' kernels at once.
+    // Consecutive proofs on the same streams cannot (stream order); `lanes` independent sets of
+    // {stream, stream2, a|b|c, h, sort(h) buffers} can: slot i uses lane i % lanes.  Lane 0 is the prover's
+    // own streams and buffers above; the extra lanes run their follow-up kernels and the final copies on
+    // their own two streams (hardware queues are few: csrc/prover.hip, GPU_MAX_HW_QUEUES).
+    struct LaneExtra {
+        hipStream_t stream = nullptr, stream2 = nullptr;
+        DevBuf<Fr> abc, h;
+        SortBufs sort_h;
+        ~LaneExtra() {
+            if (stream2 && stream2 != stream) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+            if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        }
+    };
+    static constexpr int MAX_LANES = 8;
+    std::unique_ptr<LaneExtra> extra[MAX_LANES - 1];
+    int lanes = 1;
     uint32_t wbits = 0;
     // ---- chain partitioned across the shards (ZK_FLAG_PARTITIONED_CHAIN; shard_count = 2^log_shards):
     // this prover computes rows [sh.lo, sh.hi) of a, b, c only, runs the local stages of the six
@@ -278,6 +296,8 @@ struct zk_prover {
 
     ~zk_prover() {
         // proofs may still be in flight (submitted, never collected): drain before anything is released
+        for (auto &x : extra)
+            if (x) { (void)hipStreamSynchronize(x->stream); (void)hipStreamSynchronize(x->stream2); }
         for (hipStream_t st : {stream_h2d, stream, stream2, tail_pool[0], tail_pool[1], tail_pool[2], tail_pool[3], tail_pool[4], stream_fin})
             if (st) (void)hipStreamSynchronize(st);
         if (ev_ext_in) (void)hipEventDestroy(ev_ext_in);
@@ -594,6 +614,27 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     if (p->part) p->xb.alloc(3 * p->nloc);
     p->abc_use = p->abc.p;
     p->xb_use = p->xb.p;
+    {
+        // lanes for small circuits (see zk_prover::LaneExtra).  ZKHIP_LANES=1..4 overrides.
+        const char *e = getenv("ZKHIP_LANES");
+        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 17) ? 4 : 1);
+        if (lanes < 1) lanes = 1;
+        if (lanes > zk_prover::MAX_LANES) lanes = zk_prover::MAX_LANES;
+        if (p->part || getenv("ZKHIP_SERIAL")) lanes = 1;
+        for (int l = 1; l < lanes; l++) {
+            auto x = std::make_unique<zk_prover::LaneExtra>();
+            HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+            const char *ls = getenv("ZKHIP_LANE_STREAMS");
+            const bool one_stream = ls && atoi(ls) == 1;
+            if (one_stream) x->stream2 = x->stream;
+            else HIP_TRY(hipStreamCreateWithFlags(&x->stream2, hipStreamNonBlocking));
+            x->abc.alloc(3 * p->nloc);
+            x->h.alloc(p->nloc);
+            x->sort_h.alloc(nh, wbits, p->precomp);
+            p->extra[l - 1] = std::move(x);
+        }
+        p->lanes = lanes;
+    }
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
     clk.lap(p->precomp ? "window pre-computation" : "finish", s);
     *out = p.release();
@@ -662,14 +703,28 @@ namespace {
 struct PhaseCtx {
     zk_prover *p;
     zk_prover::ProofSlot &q;
-    hipStream_t s, s2;
+    hipStream_t s, s2, sf;
+    hipStream_t tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ntails = 0;
+    Fr *abc, *h;
+    SortBufs *sort_h;
     bool tm;
     uint32_t tbw, tbh, Ww;
     uint64_t ew, eh;
     MsmPlan pw;
     G1Acc *bA, *bB1, *bC, *bH;
     PhaseCtx(zk_prover *p_, int si) : p(p_), q(p_->slot[si]) {
-        s = p->stream; s2 = p->stream2;
+        const int lane = si % p->lanes;
+        if (lane == 0) {
+            s = p->stream; s2 = p->stream2; sf = p->stream_fin;
+            for (int m = 0; m < 5; m++) tail[m] = p->tail[m];
+            ntails = p->tail_streams;
+            abc = p->abc_use; h = p->h.p; sort_h = &p->sort_h;
+        } else {
+            zk_prover::LaneExtra &x = *p->extra[lane - 1];
+            s = x.stream; s2 = x.stream2; sf = x.stream;
+            abc = x.abc.p; h = x.h.p; sort_h = &x.sort_h;
+        }
         tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
         tbw = q.sort_w.total_buckets(); tbh = p->sort_h.total_buckets();
         ew = q.sort_w.max_entries(); eh = p->sort_h.max_entries();
@@ -677,8 +732,8 @@ struct PhaseCtx {
         bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
     }
     void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
-    AccumTail tail_of(int m) const { AccumTail t; t.stream = p->tail[m]; t.l1_done = q.ev_l1[m]; return t; }
-    hipStream_t after(int m, hipStream_t own) const { return p->tail[m] ? p->tail[m] : own; }
+    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; return t; }
+    hipStream_t after(int m, hipStream_t own) const { return tail[m] ? tail[m] : own; }
     NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
 };
 
@@ -698,7 +753,7 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     if (r32) memcpy(q.r32, r32, 32);
     if (s32) memcpy(q.s32, s32, 32);
     hipStream_t s = c.s, s2 = c.s2;
-    const bool tails = p->tail_streams != 0;
+    const bool tails = c.ntails != 0;
     const bool tm = c.tm;
 
     c.mark(0);
@@ -721,7 +776,7 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     const uint64_t ew = c.ew;
     const MsmPlan pw = c.pw;
     launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
-    if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, p->tail[4]);
+    if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, c.tail[4]);
     if (p->batch_abc) {
         // small circuits: MSM A, B1 and C (same scalars, same sorted entries) in ONE set of launches —
         // level-1 accumulation, merges and bucket reduction each cost what one MSM's cost
@@ -735,13 +790,14 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
         launch_msm_accum_g1_batch(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, b, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
         if (tm) for (int e : {13, 14, 15, 16}) HIP_TRY(hipEventRecord(q.ev[e], s2));      // (B1 and C have no launch of their own)
         launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 3, pw, c.after(0, s2));
+        if (!tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
         HIP_TRY(hipEventRecord(q.ev_join, s2));
     } else {
     launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
-    if (tails) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, p->tail[0]);
+    if (tails) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, c.tail[0]);
     launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1], q.acc_key[1], q.acc_flag[1], s2, tm ? &q.ev[13] : nullptr, c.tail_of(1));
     if (tails) {
-        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, p->tail[1]);
+        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, c.tail[1]);
     } else {
         // bucket reductions stay on the stream of their MSMs
         launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
@@ -753,7 +809,7 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
     // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96) — on the rows this prover holds
     const uint64_t nl = p->nloc;
-    Fr *abc = p->abc_use;
+    Fr *abc = c.abc;
     CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
     launch_spmv_abc(abc, abc + nl, abc + 2 * nl, csr, d_wtns, (uint32_t)nl, s);
     c.mark(1);
@@ -801,10 +857,10 @@ void phase_local(zk_prover *p) {
     const uint64_t nl = p->nloc;
     NttTables tb = c.tables();
     const bool a2a = p->part && !p->have_peers;          // blocks travel through the caller's all_to_all
-    if (a2a) launch_chunk_unpack(p->abc_use, p->pk_use, 3, p->logn, p->log_shards, c.s);
-    launch_ntt_dif_inverse(p->abc_use, nl, 3, tb, c.s, local_logn);
-    launch_ntt_dit_forward(p->abc_use, nl, 3, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
-    if (a2a) launch_chunk_pack(p->pk_use, p->abc_use, 3, p->logn, p->log_shards, c.s);
+    if (a2a) launch_chunk_unpack(c.abc, p->pk_use, 3, p->logn, p->log_shards, c.s);
+    launch_ntt_dif_inverse(c.abc, nl, 3, tb, c.s, local_logn);
+    launch_ntt_dit_forward(c.abc, nl, 3, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
+    if (a2a) launch_chunk_pack(p->pk_use, c.abc, 3, p->logn, p->log_shards, c.s);
     p->phase_next = p->part ? 3 : 4;
 }
 
@@ -815,15 +871,15 @@ void phase_back(zk_prover *p) {
     zk_prover::ProofSlot &q = c.q;
     hipStream_t s = c.s;
     const uint64_t nl = p->nloc;
-    Fr *abc = p->abc_use;
+    Fr *abc = c.abc;
     if (p->part && !p->have_peers) launch_chunk_unpack(abc, p->pk_use, 3, p->logn, p->log_shards, s);
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
-    launch_abc_to_h(p->h.p, abc, abc + nl, abc + 2 * nl, nl, s);
+    launch_abc_to_h(c.h, abc, abc + nl, abc + 2 * nl, nl, s);
     c.mark(2);
-    p->sort_h.run(p->h.p + (p->part ? 0 : p->sh.lo), s);
+    c.sort_h->run(c.h + (p->part ? 0 : p->sh.lo), s);
     c.mark(3);
     // 6: MSM H (src/groth16.cpp:171-173) and its bucket reduction
-    launch_msm_accum_g1(c.bH, p->sort_h.offsets.p, p->sort_h.entries.p, p->ptsH.p, 0, 0, c.tbh, c.eh, q.acc_ws_g1[3], q.acc_key[3], q.acc_flag[3], s, c.tm ? &q.ev[17] : nullptr, c.tail_of(3));
+    launch_msm_accum_g1(c.bH, c.sort_h->offsets.p, c.sort_h->entries.p, p->ptsH.p, 0, 0, c.tbh, c.eh, q.acc_ws_g1[3], q.acc_key[3], q.acc_flag[3], s, c.tm ? &q.ev[17] : nullptr, c.tail_of(3));
     c.mark(4);
     launch_msm_reduce_g1(q.wsum_g1.p + 3 * c.Ww, q.scratch_g1.p + msm_reduce_scratch_points(3, c.pw), c.bH, 1, p->sort_h.plan, c.after(3, s));
     // MSM C (src/groth16.cpp:202-204) balances the two streams: it only needs sort(w).  (Moving it to
@@ -839,10 +895,10 @@ void phase_back(zk_prover *p) {
 
     // ---- join on the finishing stream (the main streams go straight on to the next proof):
     // window sums -> pinned host memory
-    hipStream_t sf = p->stream_fin;
+    hipStream_t sf = c.sf;
     HIP_TRY(hipStreamWaitEvent(sf, q.ev_main, 0));
     HIP_TRY(hipStreamWaitEvent(sf, q.ev_join, 0));
-    for (int i = 0; i < p->tail_streams; i++) {
+    for (int i = 0; i < c.ntails; i++) {
         HIP_TRY(hipEventRecord(q.ev_tail[i], p->tail_pool[i]));
         HIP_TRY(hipStreamWaitEvent(sf, q.ev_tail[i], 0));
     }
@@ -883,7 +939,14 @@ struct SubmittedRS {
     uint8_t r32[32], s32[32];
     bool have_r = false, have_s = false;
 };
-static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullptr) {
+// `direct` (unsharded provers): assemble the proof straight from the window sums instead of filling `out`;
+// (r32, s32) given by the caller override the ones captured at submit (synchronous zk_prove).
+struct DirectProof {
+    zk_proof *out;
+    const uint8_t *r32, *s32;
+    bool use_submitted;
+};
+static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullptr, const DirectProof *direct = nullptr) {
     std::lock_guard<std::mutex> ck(p->cmtx);
     zk_prover::ProofSlot *qp;
     {
@@ -942,6 +1005,22 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     const uint32_t cw = q.sort_w.plan.c, ch = p->sort_h.plan.c;
     const size_t P1 = sizeof(G1XYZZ);
     const uint8_t *w1 = q.w1, *w2 = q.w2;
+    if (direct) {
+        const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32 : nullptr) : direct->r32;
+        const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32 : nullptr) : direct->s32;
+        if (HostTail::finish_from_windows(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, w1, w2, Ww, cw, Wh, ch,
+                                          r32, s32, direct->out->A, direct->out->B, direct->out->C))
+            throw std::runtime_error("getrandom failed");
+        return;
+    }
+    if (Ww == 1 && Wh == 1) {          // window-precomputed tables: one sum per MSM, nothing to run in parallel
+        HostTail::combine_windows_g1(w1, Ww, cw, out->pi_a);
+        HostTail::combine_windows_g1(w1 + (size_t)Ww * P1, Ww, cw, out->pib1);
+        HostTail::combine_windows_g1(w1 + (size_t)2 * Ww * P1, Ww, cw, out->pi_c);
+        HostTail::combine_windows_g1(w1 + (size_t)3 * Ww * P1, Wh, ch, out->pih);
+        HostTail::combine_windows_g2(w2, Ww, cw, out->pi_b);
+        return;
+    }
     // five independent serial chains (W*c doublings each): one host thread per chain
     std::thread t1([&] { HostTail::combine_windows_g1(w1, Ww, cw, out->pi_a); });
     std::thread t2([&] { HostTail::combine_windows_g1(w1 + (size_t)Ww * P1, Ww, cw, out->pib1); });
@@ -957,14 +1036,14 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
 // One synchronous proof.  The witness upload, the device work and the wait all happen under the
 // prover's mutex: concurrent callers are serialised proof by proof (Prover::prove is re-entrant
 // in the reference; here the per-proof buffers are the prover's).
-void prove_msm(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, zk_msm_sums *out) {
+void prove_msm(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, zk_msm_sums *out, const DirectProof *direct = nullptr) {
     std::lock_guard<std::mutex> one(p->sync_mtx);
     {
         std::lock_guard<std::mutex> lk(p->mtx);
         if (p->in_flight) throw std::invalid_argument("asynchronous proofs in flight: collect them first");
         submit_locked(p, d_wtns, h_wtns, nullptr, nullptr);
     }
-    collect_sums(p, out);
+    collect_sums(p, out, nullptr, direct);
 }
 
 void prove_finish(zk_prover *p, const zk_msm_sums *parts, uint32_t nparts, const uint8_t *r32, const uint8_t *s32, zk_proof *out) {
@@ -1023,9 +1102,8 @@ int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uin
     return guarded([&] {
         if (!p || !d_wtns || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove on a sharded prover: use zk_prove_msm + zk_prove_finish");
-        zk_msm_sums sums;
-        prove_msm(p, (const Fr *)d_wtns, nullptr, &sums);
-        prove_finish(p, &sums, 1, r32, s32, out);
+        const DirectProof d{out, r32, s32, false};
+        prove_msm(p, (const Fr *)d_wtns, nullptr, nullptr, &d);
     });
 }
 
@@ -1033,9 +1111,8 @@ int zk_prove(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const uint8_
     return guarded([&] {
         if (!p || !wtns || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove on a sharded prover: use zk_prove_msm + zk_prove_finish");
-        zk_msm_sums sums;
-        prove_msm(p, nullptr, wtns, &sums);
-        prove_finish(p, &sums, 1, r32, s32, out);
+        const DirectProof d{out, r32, s32, false};
+        prove_msm(p, nullptr, wtns, nullptr, &d);
     });
 }
 
@@ -1078,10 +1155,8 @@ int zk_prove_collect(zk_prover *p, zk_proof *out) {
     return guarded([&] {
         if (!p || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove_collect on a sharded prover: use zk_prove_msm_collect + zk_prove_finish");
-        zk_msm_sums sums;
-        SubmittedRS rs;
-        collect_sums(p, &sums, &rs);
-        prove_finish(p, &sums, 1, rs.have_r ? rs.r32 : nullptr, rs.have_s ? rs.s32 : nullptr, out);
+        const DirectProof d{out, nullptr, nullptr, true};
+        collect_sums(p, nullptr, nullptr, &d);
     });
 }
 
