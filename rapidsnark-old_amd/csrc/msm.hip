@@ -530,8 +530,13 @@ __device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes,
 // blockIdx.y selects one of up to three MSMs over the SAME sorted entry list (A, B1, C share sort(w)):
 // small circuits launch them together — a level-1 launch there is latency-bound (a lane's chain of 32
 // adds, a grid that does not fill the chip) and three of them cost what one costs.
+#ifdef ZK_G1_FOUR_WAVES
+#define ZK_G1_L1_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define ZK_G1_L1_WAVES
+#endif
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_accum_l1(G1Acc *buckets0, const uint32_t *offsets, const uint32_t *entries,
+__global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buckets0, const uint32_t *offsets, const uint32_t *entries,
                                                       AccumBatch batch, uint32_t nbuckets_total, G1Acc *out_part0, uint32_t *out_key0,
                                                       uint32_t *out_flag0, uint32_t nlanes, uint32_t chunk_min) {
     static_assert(sizeof(F) == sizeof(Fq), "G1 only: the G2 level-1 kernel is k_msm_accum_l1_g2s");
