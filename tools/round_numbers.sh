@@ -20,7 +20,7 @@ except Exception as e:
 PY
 done
 cat $out/${tag}_shard_probe.txt
-for k in 14 16 18; do python bench.py --log2n $k --steps 100 --warmup 10 --no-cpu > $out/${tag}_bench_2p$k.json 2>/dev/null; python tools/server_bench.py $k 256 0 2>/dev/null; python tools/server_bench.py $k 256 0,0 2>/dev/null; done | tee $out/${tag}_server_throughput.txt
+for k in 14 16 18; do python bench.py --log2n $k --steps 100 --warmup 10 --no-cpu > $out/${tag}_bench_2p$k.json 2>/dev/null; python tools/server_bench.py $k 512 0 2>/dev/null; python tools/server_bench.py $k 512 0,0 2>/dev/null; done | tee $out/${tag}_server_throughput.txt
 for k in 14 16 18; do python - "$out/${tag}_bench_2p$k.json" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
