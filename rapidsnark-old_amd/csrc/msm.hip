@@ -619,7 +619,12 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
 // G2 level 1 with the accumulator split across lane pairs (curve29.hpp, Fq2s): two lanes per chunk,
 // lane parity = Fq2 component.  Both lanes of a pair walk the same entries, so the loop and every
 // branch are uniform inside the pair (the DPP exchanges need both lanes active).
-__global__ __launch_bounds__(256) void k_msm_accum_l1_g2s(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
+#ifdef ZK_G2_THREE_WAVES
+#define ZK_G2_L1_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
+#else
+#define ZK_G2_L1_WAVES
+#endif
+__global__ __launch_bounds__(256) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                           const G2Affine *points, uint32_t idx_min, uint32_t idx_sub,
                                                           uint32_t nbuckets_total, G2Acc *out_part, uint32_t *out_key,
                                                           uint32_t *out_flag, uint32_t nlanes, uint32_t chunk_min) {
