@@ -235,7 +235,17 @@ struct zk_prover {
         uint8_t r32[32], s32[32];
         bool have_r = false, have_s = false;
         bool host_witness = false;
+        // small circuits: the ~60 launches of a proof captured once as a HIP graph (per slot: every pointer in it
+        // is the slot's or the lane's) and replayed; valid for the witness address it was captured with
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        const Fr *graph_wtns = nullptr;
+        hipEvent_t ev_gdone = nullptr;      // recorded behind the graph launch: what a collect waits for
+        bool via_graph = false;
         ~ProofSlot() {
+            if (gexec) (void)hipGraphExecDestroy(gexec);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ev_gdone) (void)hipEventDestroy(ev_gdone);
             for (auto &e : ev_l1) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_done}) if (e) (void)hipEventDestroy(e);
             for (auto &e : ev_tail) if (e) (void)hipEventDestroy(e);
@@ -287,6 +297,8 @@ struct zk_prover {
     hipStream_t tail_pool[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int tail_streams = 0;
+    bool use_graph = false;     // replay captured graphs (ZKHIP_GRAPH=1; small unsharded-chain provers without timings)
+    bool capturing = false;     // the phases are being recorded into a slot's graph, not executed
     bool batch_abc = false;     // MSM A, B1, C in one set of launches (small circuits; ZKHIP_BATCH_ABC=0/1 overrides)
     hipStream_t stream_fin = nullptr;                   // joins a proof's streams and copies its window sums to the host
     hipStream_t stream_h2d = nullptr;                   // witness uploads of host-witness proofs
@@ -634,6 +646,8 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             p->extra[l - 1] = std::move(x);
         }
         p->lanes = lanes;
+        const char *ge = getenv("ZKHIP_GRAPH");
+        p->use_graph = ge && atoi(ge) != 0 && !p->part && !(p->flags & ZK_FLAG_TIMINGS) && !getenv("ZKHIP_SERIAL");
     }
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
     clk.lap(p->precomp ? "window pre-computation" : "finish", s);
@@ -766,6 +780,10 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     if (staged) {
         HIP_TRY(hipStreamWaitEvent(s, q.ev_h2d, 0));
         HIP_TRY(hipStreamWaitEvent(s2, q.ev_h2d, 0));
+    }
+    if (p->capturing && s2 != s) {       // stream 2 joins the capture (and the graph orders it behind the upload)
+        HIP_TRY(hipEventRecord(q.ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(s2, q.ev_fork, 0));
     }
     q.sort_w.run(d_wtns + p->sv.lo, s2);
     HIP_TRY(hipEventRecord(q.ev_sortw, s2));
@@ -906,8 +924,10 @@ void phase_back(zk_prover *p) {
     HIP_TRY(hipMemcpyAsync(q.w1, q.wsum_g1.p, q.w1_bytes, hipMemcpyDeviceToHost, sf));
     HIP_TRY(hipMemcpyAsync(q.w2, q.wsum_g2.p, q.w2_bytes, hipMemcpyDeviceToHost, sf));
     HIP_TRY(hipEventRecord(q.ev_done, sf));
+    if (p->capturing && sf != s) HIP_TRY(hipStreamWaitEvent(s, q.ev_done, 0));     // every forked stream rejoins the origin
     HIP_TRY(hipGetLastError());          // nothing of the ~100 launches above may have been refused
     q.busy = true;
+    q.via_graph = false;
     p->phase_open = -1;
     p->next_submit++;
     p->in_flight++;
@@ -922,9 +942,69 @@ struct PhaseAbort {
 
 }   // namespace
 
+// Graph path (small circuits): a proof's device work — everything behind the witness upload — is recorded once
+// per slot by running the same three phases under stream capture, then replayed with one hipGraphLaunch on the
+// lane's stream 1.  The upload stays outside (its source changes with every proof), and so does the event a
+// collect waits for.
+static void submit_graph(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
+    if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("too many proofs in flight (ZK_MAX_IN_FLIGHT): collect one first");
+    if (p->phase_open >= 0) throw std::invalid_argument("a proof is still being submitted phase by phase");
+    const int si = (int)(p->next_submit % ZK_MAX_IN_FLIGHT);
+    alloc_slot(p, si);
+    PhaseCtx c(p, si);
+    zk_prover::ProofSlot &q = c.q;
+    if (!q.ev_gdone) HIP_TRY(hipEventCreateWithFlags(&q.ev_gdone, hipEventDisableTiming));
+    const bool staged = h_wtns != nullptr;
+    if (staged) d_wtns = upload_witness(p, q, h_wtns);
+    if (!q.gexec || q.graph_wtns != d_wtns) {
+        if (q.gexec) { (void)hipGraphExecDestroy(q.gexec); q.gexec = nullptr; }
+        if (q.graph) { (void)hipGraphDestroy(q.graph); q.graph = nullptr; }
+        const uint32_t ns = p->next_submit, nf = p->in_flight;
+        HIP_TRY(hipStreamBeginCapture(c.s, hipStreamCaptureModeRelaxed));
+        p->capturing = true;
+        hipError_t end = hipSuccess;
+        try {
+            PhaseAbort guard{p};
+            phase_front(p, d_wtns, nullptr, r32, s32);
+            phase_local(p);
+            phase_back(p);
+            guard.armed = false;
+        } catch (...) {
+            p->capturing = false;
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(c.s, &dead);
+            if (dead) (void)hipGraphDestroy(dead);
+            p->next_submit = ns; p->in_flight = nf; q.busy = false;
+            throw;
+        }
+        p->capturing = false;
+        end = hipStreamEndCapture(c.s, &q.graph);
+        p->next_submit = ns; p->in_flight = nf; q.busy = false;      // the capture ran the bookkeeping of a submit: undo
+        HIP_TRY(end);
+        HIP_TRY(hipGraphInstantiate(&q.gexec, q.graph, nullptr, nullptr, 0));
+        q.graph_wtns = d_wtns;
+    }
+    q.host_witness = staged;
+    q.have_r = r32 != nullptr;
+    q.have_s = s32 != nullptr;
+    if (r32) memcpy(q.r32, r32, 32);
+    if (s32) memcpy(q.s32, s32, 32);
+    if (staged) HIP_TRY(hipStreamWaitEvent(c.s, q.ev_h2d, 0));
+    HIP_TRY(hipGraphLaunch(q.gexec, c.s));
+    HIP_TRY(hipEventRecord(q.ev_gdone, c.s));
+    q.busy = true;
+    q.via_graph = true;
+    p->next_submit++;
+    p->in_flight++;
+}
+
 static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
     if (p->part) throw std::invalid_argument("this prover holds one block of a partitioned chain: drive it through zk_multi_prove* or zk_shard_*");
     DeviceGuard g(p->device);
+    if (p->use_graph) {
+        submit_graph(p, d_wtns, h_wtns, r32, s32);
+        return;
+    }
     PhaseAbort guard{p};
     phase_front(p, d_wtns, h_wtns, r32, s32);
     phase_local(p);
@@ -956,7 +1036,7 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     }
     zk_prover::ProofSlot &q = *qp;
     DeviceGuard g(p->device);
-    const hipError_t done = hipEventSynchronize(q.ev_done);
+    const hipError_t done = hipEventSynchronize(q.via_graph ? q.ev_gdone : q.ev_done);
     // the slot is retired whatever happens below (a failed proof must not wedge the queue), but only
     // AFTER the wait and the host tail: nobody may reuse its buffers while they are still read
     struct Retire {
