@@ -14,8 +14,9 @@ const char *get_error();
 struct HostTail {
     // Window-sum Horner: out = sum_w 2^(c*w) * windows[w]; windows are XYZZ in device layout
     // (G1: 4 x 32 B, G2: 4 x 64 B per point).  Result affine Montgomery (zero = infinity).
-    static void combine_windows_g1(const uint8_t *windows_xyzz, uint32_t W, uint32_t c, uint8_t out_affine[64]);
-    static void combine_windows_g2(const uint8_t *windows_xyzz, uint32_t W, uint32_t c, uint8_t out_affine[128]);
+    // rc records per window (kernels.hpp, msm_wsum_rc): 1 = the window's sum, c = the bit sums T, S_0 .. S_{c-2}
+    static void combine_windows_g1(const uint8_t *windows_xyzz, uint32_t W, uint32_t c, uint32_t rc, uint8_t out_affine[64]);
+    static void combine_windows_g2(const uint8_t *windows_xyzz, uint32_t W, uint32_t c, uint32_t rc, uint8_t out_affine[128]);
     // out += in (affine Montgomery, zero = infinity): adds shard partial sums
     static void add_affine_g1(uint8_t acc[64], const uint8_t in[64]);
     static void add_affine_g2(uint8_t acc[128], const uint8_t in[128]);
@@ -30,7 +31,7 @@ struct HostTail {
     // like the reference's randombytes_buf(31 bytes).  Returns nonzero when the random source fails.
     static int finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
                                    const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
-                                   const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t Wh, uint32_t ch,
+                                   const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
                                    const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
     // canonical base-10 of a 32-byte LE integer
     static std::string to_dec(const uint8_t le32[32]);

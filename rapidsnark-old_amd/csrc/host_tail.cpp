@@ -28,27 +28,39 @@ typedef XYZZ<Fq2h> G2P;
 
 static_assert(sizeof(G1A) == 64 && sizeof(G2A) == 128 && sizeof(G1P) == 128 && sizeof(G2P) == 256, "layout");
 
+// One bucket set's sum from its rc records: rc = 1: the sum itself; rc = c: T, S_0 .. S_{c-2} of the bit-sum
+// reduction (msm.hip): sum_k (k+1) B_k = T + sum_j 2^j S_j — a serial chain of c-1 doublings, microseconds here.
 template <class PT>
-static PT horner(const uint8_t *w, uint32_t W, uint32_t c) {
+static PT set_sum(const uint8_t *w, uint32_t rc) {
+    PT acc = PT::inf(), s;
+    for (uint32_t j = rc - 1; j >= 1; j--) {
+        if (!acc.is_inf()) acc = dbl(acc);
+        memcpy(&s, w + (size_t)j * sizeof(PT), sizeof(PT));
+        add(acc, s);
+    }
+    memcpy(&s, w, sizeof(PT));
+    add(acc, s);
+    return acc;
+}
+template <class PT>
+static PT horner(const uint8_t *w, uint32_t W, uint32_t c, uint32_t rc) {
     PT acc = PT::inf();
     for (int i = (int)W - 1; i >= 0; i--) {
         if (!acc.is_inf()) for (uint32_t k = 0; k < c; k++) acc = dbl(acc);
-        PT s;
-        memcpy(&s, w + (size_t)i * sizeof(PT), sizeof(PT));
-        add(acc, s);
+        add(acc, set_sum<PT>(w + (size_t)i * rc * sizeof(PT), rc));
     }
     return acc;
 }
 template <class PT, class AT>
-static void combine_windows(const uint8_t *w, uint32_t W, uint32_t c, uint8_t *out) {
-    AT a = to_affine(horner<PT>(w, W, c));
+static void combine_windows(const uint8_t *w, uint32_t W, uint32_t c, uint32_t rc, uint8_t *out) {
+    AT a = to_affine(horner<PT>(w, W, c, rc));
     memcpy(out, &a, sizeof(AT));
 }
-void HostTail::combine_windows_g1(const uint8_t *w, uint32_t W, uint32_t c, uint8_t out[64]) {
-    combine_windows<G1P, G1A>(w, W, c, out);
+void HostTail::combine_windows_g1(const uint8_t *w, uint32_t W, uint32_t c, uint32_t rc, uint8_t out[64]) {
+    combine_windows<G1P, G1A>(w, W, c, rc, out);
 }
-void HostTail::combine_windows_g2(const uint8_t *w, uint32_t W, uint32_t c, uint8_t out[128]) {
-    combine_windows<G2P, G2A>(w, W, c, out);
+void HostTail::combine_windows_g2(const uint8_t *w, uint32_t W, uint32_t c, uint32_t rc, uint8_t out[128]) {
+    combine_windows<G2P, G2A>(w, W, c, rc, out);
 }
 
 template <class PT, class AT>
@@ -292,30 +304,30 @@ static int draw31(uint8_t out[32]) {
 // no detour through the affine zk_msm_sums record (five inversions) that sharded provers exchange.
 int HostTail::finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
                                   const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
-                                  const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t Wh, uint32_t ch,
+                                  const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
     uint8_t r[32], s[32];
     if (r32) memcpy(r, r32, 32); else if (draw31(r)) return 1;
     if (s32) memcpy(s, s32, 32); else if (draw31(s)) return 1;
-    const size_t P1 = sizeof(G1P);
+    const size_t M1 = (size_t)Ww * rcw * sizeof(G1P);      // one MSM's records
     G1P a, b1, c, h;
     G2P b2;
     if (Ww > 1 || Wh > 1) {            // plain tables: five Horner chains of W*c doublings, one host thread each
-        std::thread t1([&] { a = horner<G1P>(w1, Ww, cw); });
-        std::thread t2([&] { b1 = horner<G1P>(w1 + (size_t)Ww * P1, Ww, cw); });
-        std::thread t3([&] { c = horner<G1P>(w1 + (size_t)2 * Ww * P1, Ww, cw); });
-        std::thread t4([&] { h = horner<G1P>(w1 + (size_t)3 * Ww * P1, Wh, ch); });
-        b2 = horner<G2P>(w2, Ww, cw);
+        std::thread t1([&] { a = horner<G1P>(w1, Ww, cw, rcw); });
+        std::thread t2([&] { b1 = horner<G1P>(w1 + M1, Ww, cw, rcw); });
+        std::thread t3([&] { c = horner<G1P>(w1 + 2 * M1, Ww, cw, rcw); });
+        std::thread t4([&] { h = horner<G1P>(w1 + 3 * M1, Wh, ch, rch); });
+        b2 = horner<G2P>(w2, Ww, cw, rcw);
         t1.join();
         t2.join();
         t3.join();
         t4.join();
     } else {
-        a = horner<G1P>(w1, Ww, cw);
-        b1 = horner<G1P>(w1 + (size_t)Ww * P1, Ww, cw);
-        c = horner<G1P>(w1 + (size_t)2 * Ww * P1, Ww, cw);
-        h = horner<G1P>(w1 + (size_t)3 * Ww * P1, Wh, ch);
-        b2 = horner<G2P>(w2, Ww, cw);
+        a = horner<G1P>(w1, Ww, cw, rcw);
+        b1 = horner<G1P>(w1 + M1, Ww, cw, rcw);
+        c = horner<G1P>(w1 + 2 * M1, Ww, cw, rcw);
+        h = horner<G1P>(w1 + 3 * M1, Wh, ch, rch);
+        b2 = horner<G2P>(w2, Ww, cw, rcw);
     }
     assemble_core(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, h, a, b1, b2, c, r, s, outA, outB, outC);
     return 0;

@@ -156,6 +156,9 @@ void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t
 void launch_msm_reduce_g1(G1XYZZ *window_sums, G1Acc *scratch, const G1Acc *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 void launch_msm_reduce_g2(G2XYZZ *window_sums, G2Acc *scratch, const G2Acc *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s);
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p);
+// window-sum records per bucket set the reduction writes: 1 (the set's sum) or, for small sets, c (T, S_0 .. S_{c-2}:
+// set sum = T + sum_j 2^j S_j, finished on the host); layout [msm][set][record]
+uint32_t msm_wsum_rc(MsmPlan p);
 
 // MSM tables live in HBM as canonical words of x*2^261 (the 29-bit-limb kernels' Montgomery radix);
 // converts n coordinates in place from the zkey's x*2^256.

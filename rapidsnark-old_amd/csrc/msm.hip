@@ -898,6 +898,89 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out,
     }
 }
 
+// ---- bit-sum reduction: small bucket sets ---------------------------------------------------------------
+// sum_k (k+1) B_k = T + sum_j 2^j S_j with T = sum_k B_k and S_j = sum of the buckets whose index has bit j
+// set.  The c sums (T, S_0 .. S_{c-2}) come out of ONE binary tree: a block of 2^m buckets carries m+1 sums;
+// joining siblings L (bit m clear) and R (bit m set) is  T = T_L + T_R,  S_j = S_j^L + S_j^R (j < m),
+// S_m = T_R  — m+1 INDEPENDENT additions per join, so every level is one addition deep and the whole
+// reduction is c-1 additions deep (≈ 0.1 ms), where the chunked form above is a serial chain of 2*chunk
+// additions plus a ~c-step double-and-add per lane and then an LDS tree (0.35-0.5 ms per launch pair, a third
+// of a small proof's kernel time).  The c sums go to the host, whose serial Horner over c-1 bits costs
+// microseconds.  Used while a launch reduces at most 2^16 buckets (circuits up to 2^18 constraints); the chunked
+// form stays for the large sets, where work, not depth, is what counts.  In place: a block of size 2^m keeps T in its slot 0 and S_j in slot 1+j.
+#define BITS_RS 16u         // slots per block record in global memory (>= c <= 16)
+template <class F>
+__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_block(ACCMEM *rec, XYZZ<F> *final_out, const ACCMEM *buckets,
+                                                                         uint32_t nbuckets, uint32_t c, uint32_t nblk) {
+    extern __shared__ uint32_t lds_raw[];
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    constexpr uint32_t NE = REDUCE_THREADS / LM::LPE;           // buckets per workgroup: 256 (G1), 128 (G2)
+    constexpr uint32_t LB = LM::LPE == 1 ? 8u : 7u;
+    XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);      // slot s of the block: lds[s * LPE + component]
+    const uint32_t e = threadIdx.x / LM::LPE, comp = threadIdx.x % LM::LPE;
+    const uint32_t group = blockIdx.y, blk = blockIdx.x;
+    const uint32_t k = blk * NE + e;
+    lds[threadIdx.x] = k < nbuckets ? LM::load(buckets + (uint64_t)group * nbuckets + k) : XYZZ<FR>::inf();
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t m = 0; m < LB; m++) {
+        const uint32_t per = m + 2, ng = NE >> (m + 1);
+        const uint32_t g = e / per, i = e % per;
+        if (g < ng) {
+            const uint32_t L = g << (m + 1), R = L + (1u << m);
+            if (i <= m) {                                   // i = 0: T; i = 1 + j: S_j
+                XYZZ<FR> a = lds[(L + i) * LM::LPE + comp];
+                add(a, lds[(R + i) * LM::LPE + comp]);
+                lds[(L + i) * LM::LPE + comp] = a;
+            } else if (m >= 2) {                            // S_m = T_R (for m < 2 that slot IS R's slot 0)
+                lds[(L + m + 1) * LM::LPE + comp] = lds[R * LM::LPE + comp];
+            }
+        }
+        __syncthreads();
+    }
+    if (e <= LB && e < c) {
+        const XYZZ<FR> v = lds[threadIdx.x];
+        if (nblk == 1) LM::store256(final_out + (uint64_t)group * c + e, v);
+        else LM::store(rec + ((uint64_t)group * nblk + blk) * BITS_RS + e, v);
+    }
+}
+// the levels above the blocks, one workgroup per bucket set, on the block records in global memory
+template <class F>
+__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_top(XYZZ<F> *final_out, ACCMEM *rec, uint32_t nblk, uint32_t c) {
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    constexpr uint32_t NE = REDUCE_THREADS / LM::LPE;
+    constexpr uint32_t LB = LM::LPE == 1 ? 8u : 7u;
+    const uint32_t e = threadIdx.x / LM::LPE;
+    ACCMEM *R0 = rec + (uint64_t)blockIdx.x * nblk * BITS_RS;
+#pragma unroll 1
+    for (uint32_t m = LB; m + 1 < c; m++) {
+        const uint32_t span = 1u << (m - LB), per = m + 2, ntasks = (nblk >> (m - LB + 1)) * per;
+#pragma unroll 1
+        for (uint32_t t = e; t < ntasks; t += NE) {
+            const uint32_t g = t / per, i = t % per;
+            ACCMEM *L = R0 + (uint64_t)g * 2u * span * BITS_RS, *R = L + (uint64_t)span * BITS_RS;
+            if (i <= m) {
+                XYZZ<FR> a = LM::load(L + i);
+                add(a, LM::load(R + i));
+                LM::store(L + i, a);
+            } else {
+                LM::store(L + m + 1, LM::load(R));
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (e < c) LM::store256(final_out + (uint64_t)blockIdx.x * c + e, LM::load(R0 + e));
+}
+static inline bool reduce_bits_for(MsmPlan p) {
+    static const int forced = [] { const char *e = getenv("ZKHIP_REDUCE_BITS"); return e ? atoi(e) : -1; }();
+    if (p.c > BITS_RS || (uint64_t)p.sets * p.nbuckets > (1u << 16)) return false;      // large sets: work, not depth, counts (2^22 with plain tables: +0.6 %)
+    return forced < 0 ? true : forced != 0;
+}
+uint32_t msm_wsum_rc(MsmPlan p) { return reduce_bits_for(p) ? p.c : 1u; }
+
 // Buckets per lane of k_msm_reduce_chunks.  16 is the cheapest in total work (2 adds per bucket + one ~20-op
 // scalar multiplication per chunk); but a lane's chain is serial (32 + ~20 general adds of ~7 us each), and
 // with few buckets (small circuits, shards) the launch is a handful of waves whose latency — not work — is
@@ -913,6 +996,7 @@ static inline uint32_t reduce_chunk_for(MsmPlan p) {
 
 // scratch: chunk sums + the intermediate levels of the tree (a geometric tail)
 uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
+    if (reduce_bits_for(p)) return (uint64_t)n_msm * p.sets * (p.nbuckets / 128u + 1u) * BITS_RS;      // block records (G2 blocks are the smaller)
     uint64_t groups = (uint64_t)n_msm * p.sets, cnt = p.nbuckets / reduce_chunk_for(p), total = 0;
     for (;;) {
         total += groups * cnt;
@@ -1180,6 +1264,15 @@ void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t
 
 template <class F>
 static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
+    if (reduce_bits_for(p)) {          // c sums per bucket set (msm_wsum_rc), the host finishes
+        const uint32_t NE = REDUCE_THREADS / LaneModel<F>::LPE, groups = n_msm * p.sets;
+        const uint32_t nblk = p.nbuckets > NE ? p.nbuckets / NE : 1u;
+        const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename LaneModel<F>::R>);
+        hipLaunchKernelGGL(k_msm_reduce_bits_block<F>, dim3(nblk, groups), dim3(REDUCE_THREADS), lds, s, scratch, window_sums, buckets, p.nbuckets, p.c, nblk);
+        if (nblk > 1) hipLaunchKernelGGL(k_msm_reduce_bits_top<F>, dim3(groups), dim3(REDUCE_THREADS), 0, s, window_sums, scratch, nblk, p.c);
+        ZK_LAUNCH_OK("msm bucket reduction (bit sums)");
+        return;
+    }
     uint32_t chunk = reduce_chunk_for(p);
     uint32_t cnt = p.nbuckets / chunk;
     const uint32_t groups = n_msm * p.sets;

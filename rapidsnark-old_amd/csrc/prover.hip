@@ -374,9 +374,10 @@ static void alloc_slot(zk_prover *p, int i) {
     q.buckets_g1.alloc(3 * tbw + tbh);
     q.buckets_g2.alloc(tbw);
     q.scratch_g1.alloc(msm_reduce_scratch_points(3, pw) + msm_reduce_scratch_points(1, ph));
-    q.wsum_g1.alloc(3 * pw.sets + ph.sets);
+    const uint64_t ew = (uint64_t)pw.sets * msm_wsum_rc(pw), eh = (uint64_t)ph.sets * msm_wsum_rc(ph);     // window-sum records per MSM
+    q.wsum_g1.alloc(3 * ew + eh);
     q.scratch_g2.alloc(msm_reduce_scratch_points(1, pw));
-    q.wsum_g2.alloc(pw.sets);
+    q.wsum_g2.alloc(ew);
     const uint64_t slots = msm_accum_workspace_slots(q.sort_w.max_entries()), slots_h = msm_accum_workspace_slots(p->sort_h.max_entries());
     q.acc_stride = slots;
     q.acc_ws_g1_all.alloc(3 * slots + slots_h);
@@ -389,8 +390,8 @@ static void alloc_slot(zk_prover *p, int i) {
         q.acc_key[m] = q.acc_key_all.p + at;
         q.acc_flag[m] = q.acc_flag_all.p + at;
     }
-    q.w1_bytes = (size_t)(3 * pw.sets + ph.sets) * sizeof(G1XYZZ);
-    q.w2_bytes = (size_t)pw.sets * sizeof(G2XYZZ);
+    q.w1_bytes = (size_t)(3 * ew + eh) * sizeof(G1XYZZ);
+    q.w2_bytes = (size_t)ew * sizeof(G2XYZZ);
     HIP_TRY(hipHostMalloc((void **)&q.w1, q.w1_bytes, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&q.w2, q.w2_bytes, hipHostMallocDefault));
     for (auto &e : q.ev_l1) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -742,7 +743,7 @@ struct PhaseCtx {
         tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
         tbw = q.sort_w.total_buckets(); tbh = p->sort_h.total_buckets();
         ew = q.sort_w.max_entries(); eh = p->sort_h.max_entries();
-        pw = q.sort_w.plan; Ww = pw.sets;
+        pw = q.sort_w.plan; Ww = pw.sets * msm_wsum_rc(pw);      // records of one witness MSM in the window-sum arrays
         bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
     }
     void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
@@ -1082,31 +1083,33 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
         p->timings[ZK_T_WTNS_H2D] = h2d;             // witness upload (own stream; 0 for device-witness proofs)
     }
     const uint32_t Ww = q.sort_w.plan.sets, Wh = p->sort_h.plan.sets;
+    const uint32_t rcw = msm_wsum_rc(q.sort_w.plan), rch = msm_wsum_rc(p->sort_h.plan);
+    const size_t M1 = (size_t)Ww * rcw * sizeof(G1XYZZ);          // one witness MSM's records
     const uint32_t cw = q.sort_w.plan.c, ch = p->sort_h.plan.c;
     const size_t P1 = sizeof(G1XYZZ);
     const uint8_t *w1 = q.w1, *w2 = q.w2;
     if (direct) {
         const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32 : nullptr) : direct->r32;
         const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32 : nullptr) : direct->s32;
-        if (HostTail::finish_from_windows(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, w1, w2, Ww, cw, Wh, ch,
+        if (HostTail::finish_from_windows(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, w1, w2, Ww, cw, rcw, Wh, ch, rch,
                                           r32, s32, direct->out->A, direct->out->B, direct->out->C))
             throw std::runtime_error("getrandom failed");
         return;
     }
     if (Ww == 1 && Wh == 1) {          // window-precomputed tables: one sum per MSM, nothing to run in parallel
-        HostTail::combine_windows_g1(w1, Ww, cw, out->pi_a);
-        HostTail::combine_windows_g1(w1 + (size_t)Ww * P1, Ww, cw, out->pib1);
-        HostTail::combine_windows_g1(w1 + (size_t)2 * Ww * P1, Ww, cw, out->pi_c);
-        HostTail::combine_windows_g1(w1 + (size_t)3 * Ww * P1, Wh, ch, out->pih);
-        HostTail::combine_windows_g2(w2, Ww, cw, out->pi_b);
+        HostTail::combine_windows_g1(w1, Ww, cw, rcw, out->pi_a);
+        HostTail::combine_windows_g1(w1 + M1, Ww, cw, rcw, out->pib1);
+        HostTail::combine_windows_g1(w1 + 2 * M1, Ww, cw, rcw, out->pi_c);
+        HostTail::combine_windows_g1(w1 + 3 * M1, Wh, ch, rch, out->pih);
+        HostTail::combine_windows_g2(w2, Ww, cw, rcw, out->pi_b);
         return;
     }
     // five independent serial chains (W*c doublings each): one host thread per chain
-    std::thread t1([&] { HostTail::combine_windows_g1(w1, Ww, cw, out->pi_a); });
-    std::thread t2([&] { HostTail::combine_windows_g1(w1 + (size_t)Ww * P1, Ww, cw, out->pib1); });
-    std::thread t3([&] { HostTail::combine_windows_g1(w1 + (size_t)2 * Ww * P1, Ww, cw, out->pi_c); });
-    std::thread t4([&] { HostTail::combine_windows_g1(w1 + (size_t)3 * Ww * P1, Wh, ch, out->pih); });
-    HostTail::combine_windows_g2(w2, Ww, cw, out->pi_b);
+    std::thread t1([&] { HostTail::combine_windows_g1(w1, Ww, cw, rcw, out->pi_a); });
+    std::thread t2([&] { HostTail::combine_windows_g1(w1 + M1, Ww, cw, rcw, out->pib1); });
+    std::thread t3([&] { HostTail::combine_windows_g1(w1 + 2 * M1, Ww, cw, rcw, out->pi_c); });
+    std::thread t4([&] { HostTail::combine_windows_g1(w1 + 3 * M1, Wh, ch, rch, out->pih); });
+    HostTail::combine_windows_g2(w2, Ww, cw, rcw, out->pi_b);
     t1.join();
     t2.join();
     t3.join();
@@ -1672,8 +1675,9 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
     wflag.alloc(slots);
     buckets.alloc(sb.total_buckets());
     scratch.alloc(msm_reduce_scratch_points(1, sb.plan));
-    wsum.alloc(sb.plan.sets);
-    std::vector<uint8_t> w((size_t)sb.plan.sets * sizeof(XT));
+    const uint32_t rc = msm_wsum_rc(sb.plan);
+    wsum.alloc((uint64_t)sb.plan.sets * rc);
+    std::vector<uint8_t> w((size_t)sb.plan.sets * rc * sizeof(XT));
     if constexpr (sizeof(AffT) == 64) {
         launch_msm_accum_g1((G1Acc *)buckets.p, sb.offsets.p, sb.entries.p, (const G1Affine *)pts.p, 0, 0, sb.total_buckets(), emax, (G1Acc *)ws.p, wkey.p, wflag.p, 0);
         launch_msm_reduce_g1((G1XYZZ *)wsum.p, (G1Acc *)scratch.p, (const G1Acc *)buckets.p, 1, sb.plan, 0);
@@ -1682,8 +1686,8 @@ static void msm_generic(uint8_t *out, const uint8_t *bases, const uint8_t *scala
         launch_msm_reduce_g2((G2XYZZ *)wsum.p, (G2Acc *)scratch.p, (const G2Acc *)buckets.p, 1, sb.plan, 0);
     }
     HIP_TRY(hipMemcpy(w.data(), wsum.p, w.size(), hipMemcpyDeviceToHost));
-    if (g2) HostTail::combine_windows_g2(w.data(), sb.plan.sets, sb.plan.c, out);
-    else HostTail::combine_windows_g1(w.data(), sb.plan.sets, sb.plan.c, out);
+    if (g2) HostTail::combine_windows_g2(w.data(), sb.plan.sets, sb.plan.c, rc, out);
+    else HostTail::combine_windows_g1(w.data(), sb.plan.sets, sb.plan.c, rc, out);
 }
 
 template <class AffT, class XT, class FT>
