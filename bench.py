@@ -189,6 +189,14 @@ def main():
         for i in range(warmup):
             submit(i)
             collect()
+        if pipelined and warmup:
+            # still untimed: fill the pipeline once, so that every proof slot the timed loop uses exists (a slot's
+            # buffers are allocated the first time its depth is reached)
+            depth0 = args.in_flight or default_depth(k, in_hbm)
+            for i in range(depth0):
+                submit(i)
+            for i in range(depth0):
+                collect()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -206,11 +214,15 @@ def main():
                 # the GIL for both calls.
                 import threading
                 free = threading.Semaphore(depth)
+                ready = threading.Semaphore(0)            # proofs submitted and not yet collected
                 errors = []
 
                 def collector():
                     try:
                         for _ in range(steps):
+                            ready.acquire()               # never ask for a proof that has not been submitted yet
+                            if errors:
+                                return
                             collect()
                             add_timings()
                             free.release()
@@ -225,11 +237,19 @@ def main():
                     free.acquire()
                     if errors:
                         break
-                    submit(warmup + i)
+                    try:
+                        submit(warmup + i)
+                    except Exception as exc:              # noqa: BLE001
+                        errors.append(exc)
+                        for _ in range(steps):
+                            ready.release()
+                        break
+                    ready.release()
                     if not started:
                         th.start()
                         started = True
-                th.join()
+                if started:
+                    th.join()
                 if errors:
                     raise errors[0]
             else:
