@@ -209,7 +209,7 @@ def main():
             depth = args.in_flight or default_depth(k, in_hbm)
             if world == 1 and args.collector_thread:
                 # two host threads, as a server would run them: this one submits, the other collects (wait for
-                # the GPU + ≈1 ms of host tail per proof: Horner over the window sums, final assembly).  The
+                # the GPU + 0.3 ms of host tail per proof: window sums, final assembly).  The
                 # library holds its submission mutex only around bookkeeping during a collect; ctypes drops
                 # the GIL for both calls.
                 import threading

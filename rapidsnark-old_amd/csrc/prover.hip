@@ -181,9 +181,8 @@ struct zk_prover {
     uint8_t vk_alpha1[64], vk_beta1[64], vk_beta2[128], vk_delta1[64], vk_delta2[128];
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: witness-only MSM chain (A,B1,C,B2)
     // mtx: submission + slot bookkeeping.  cmtx: serialises collectors; a collect holds mtx only to look the
-    // slot up and to retire it, NOT while it waits for the GPU and runs the host tail (≈ 1 ms of Horner +
-    // final assembly per proof: on small circuits that host time, not the GPU, bounds a one-thread
-    // submit/collect loop — a second thread collecting while the first submits removes it).
+    // slot up and to retire it, NOT while it waits for the GPU and runs the host tail (0.3 ms: window sums +
+    // final assembly) — a second thread collecting while the first submits keeps both off each other's path.
     // sync_mtx: one synchronous zk_prove* call at a time.
     std::mutex mtx, cmtx, sync_mtx;
 
