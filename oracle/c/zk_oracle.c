@@ -10,7 +10,7 @@
  * The arithmetic the reference takes from its ABSENT `depends/ffiasm` submodule
  * (.gitmodules:7-9, no pinned commit recoverable) is restated from its published algorithm:
  * 4x64-bit Montgomery (R = 2^256), radix-2 bit-reversal FFT, Pippenger multiexp with
- * per-task bucket arrays (window x point-slice), window in [2,16] from a cost model, Horner over windows.
+ * per-task bucket arrays (window x point-slice), window c = clamp(log2(n/2), 2, 16) as BASELINE.md states, Horner over windows.
  * It is "a restatement of rapidsnark's CPU algorithm", NOT ffiasm: hand-written ADX assembly
  * may be 1.3-2x faster than this compiler-generated code (say so next to any timing).
  *
@@ -334,23 +334,37 @@ static void f2_inv(fe2 *r, const fe2 *x) {
         free(buckets); free(wsum);                                                                                     \
     }
 
-/* window bits c (ffiasm clamps to [2,16]) and slices-per-window from a cost model in point
- * additions: W * (n [accumulate] + tpw * 2^c [fold slices] + 2 * 2^c [running sums]) */
+/* window bits: c = clamp(floor(log2(n / 2)), 2, 16) — the rule BASELINE.md §2 states for the reference's
+ * Pippenger (ffiasm clamps to [2,16]); only the number of point slices per window (how the nt threads are
+ * spread over W windows) is chosen here.  ZK_ORACLE_WINDOW=cost restores the round-1 cost model over c
+ * (identical choice, c = 16, from 2^17 points up). */
 static void choose_plan(uint64_t n, int nt, int *c_out, int *tpw_out) {
-    double best = 1e300;
-    int bc = 2, bt = 1;
-    for (int c = 2; c <= 16; c++) {
-        int W = (256 + c - 1) / c;
-        int tpw = nt / W;
-        if (tpw < 1) tpw = 1;
-        if ((uint64_t)tpw > n) tpw = (int)n;
-        double nb = (double)((uint64_t)1 << c);
-        int par = W * tpw < nt ? W * tpw : nt;
-        double cost = W * ((double)n + (tpw > 1 ? tpw * nb : 0.0) + 2.0 * nb) / par + 2.0 * nb / 4.0;
-        if (cost < best) { best = cost; bc = c; bt = tpw; }
+    const char *mode = getenv("ZK_ORACLE_WINDOW");
+    int c = 2;
+    if (mode && !strcmp(mode, "cost")) {
+        double best = 1e300;
+        for (int cc = 2; cc <= 16; cc++) {
+            int W = (256 + cc - 1) / cc;
+            int tpw = nt / W;
+            if (tpw < 1) tpw = 1;
+            if ((uint64_t)tpw > n) tpw = (int)n;
+            double nb = (double)((uint64_t)1 << cc);
+            int par = W * tpw < nt ? W * tpw : nt;
+            double cost = W * ((double)n + (tpw > 1 ? tpw * nb : 0.0) + 2.0 * nb) / par + 2.0 * nb / 4.0;
+            if (cost < best) { best = cost; c = cc; }
+        }
+    } else {
+        uint64_t h = n / 2;
+        int lg = 0;
+        while (h > 1) { h >>= 1; lg++; }
+        c = lg < 2 ? 2 : (lg > 16 ? 16 : lg);
     }
-    *c_out = bc;
-    *tpw_out = bt;
+    int W = (256 + c - 1) / c;
+    int tpw = nt / W;
+    if (tpw < 1) tpw = 1;
+    if ((uint64_t)tpw > n) tpw = (int)(n ? n : 1);
+    *c_out = c;
+    *tpw_out = tpw;
 }
 /* unsigned c-bit digit w of a 256-bit LE scalar */
 static inline uint32_t get_digit(const uint8_t *s, int w, int c) {
