@@ -423,7 +423,7 @@ def plan_window_bits(n, world, precomp):
 class ProverFromView:
     """zk.Prover over an in-memory view (numpy arrays) instead of a .zkey file."""
 
-    def __init__(self, zk, wl, device, shard_index, shard_count, window_bits, timings, precomp=False, partitioned_chain=False):
+    def __init__(self, zk, wl, device, shard_index, shard_count, window_bits, timings, precomp=False, partitioned_chain=False, batch=0):
         import ctypes as C
         from rapidsnark_old_amd import lib as L
         self.L = L
@@ -440,7 +440,7 @@ class ProverFromView:
                 setattr(v, name + "_bytes", a.size)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
                       (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
-                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0))
+                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0), batch)
         self.h = C.c_void_p()
         L.check(self.lib.zk_prover_create(C.byref(self.h), C.byref(v), C.byref(o)))
         self.keep = []
@@ -456,6 +456,22 @@ class ProverFromView:
 
     def submit_dev(self, ptr):
         self.L.check(self.lib.zk_prove_dev_submit(self.h, self.C.c_void_p(ptr), None, None))
+
+    def submit_batch(self, ws, rs=None):
+        """zk_prove_batch_submit: numpy uint8 witnesses (kept alive by the caller until collected)."""
+        n = len(ws)
+        ptrs = (self.C.c_void_p * n)(*[w.ctypes.data for w in ws])
+        rb = sb = None
+        if rs is not None:
+            rb = np.frombuffer(b"".join(int(r).to_bytes(32, "little") for r, _ in rs), dtype=np.uint8).copy()
+            sb = np.frombuffer(b"".join(int(s_).to_bytes(32, "little") for _, s_ in rs), dtype=np.uint8).copy()
+        self.L.check(self.lib.zk_prove_batch_submit(self.h, ptrs, n, rb.ctypes.data if rb is not None else None,
+                                                    sb.ctypes.data if sb is not None else None))
+
+    def collect_batch(self, n):
+        out = (self.L.zk_proof * n)()
+        self.L.check(self.lib.zk_prove_batch_collect(self.h, out, n))
+        return [bytes(o) for o in out]
 
     @staticmethod
     def _k32(x):

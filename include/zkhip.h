@@ -54,7 +54,11 @@ typedef struct zk_opts {
     uint32_t shard_count;    /*   point table (contiguous index slices); 0 or 1 = whole    */
     uint32_t window_bits;    /* Pippenger window c; 0 = choose from the size                           */
     uint32_t flags;          /* ZK_FLAG_* */
+    uint32_t batch;          /* 0/1 = one witness per submission; 2..ZK_MAX_BATCH = up to that many witnesses of this
+                              * circuit proved by ONE set of kernel launches (zk_prove_batch_*; small circuits, where a
+                              * proof is bound by kernel latencies: DESIGN.md section 5).  Needs ZK_FLAG_PRECOMP, unsharded. */
 } zk_opts;
+#define ZK_MAX_BATCH 8
 
 #define ZK_FLAG_TIMINGS 1u   /* record per-stage hipEvent timings (zk_prover_timings) */
 #define ZK_FLAG_PARTITIONED_CHAIN 4u   /* sharded provers only (shard_count 2, 4 or 8): the A.w/B.w rows and the six
@@ -128,6 +132,17 @@ int zk_host_alloc(void **out, size_t bytes);
 void zk_host_free(void *ptr);
 int zk_prove_collect(zk_prover *p, zk_proof *out);
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);
+/* Batched proving (a prover created with opts.batch = B >= 2): `count` (1..B) witnesses of the circuit, given as
+ * `count` host pointers, are proved by ONE submission — one digit sort with a bucket set per witness, one set of
+ * accumulation / merge / reduction launches over all of them, the A.w/B.w rows and the transforms batched — which is
+ * what a server for Semaphore-class circuits wants: there a proof is a chain of ~60 latency-bound kernels, and four
+ * proofs in one chain cost little more than one.  The reference has no counterpart (one
+ * Prover::prove per request, src/fullprover.cpp:154-159); every proof is the one zk_prove would give for the same
+ * (witness, r, s).  r32s / s32s: count x 32 bytes or NULL (drawn at collect).  A submission occupies one of the
+ * ZK_MAX_IN_FLIGHT slots; zk_prove_batch_collect takes the OLDEST submission, which must carry `count` proofs.  The
+ * single-witness entry points work on a batch prover too (a submission of one). */
+int zk_prove_batch_submit(zk_prover *p, const uint8_t *const *wtns, uint32_t count, const uint8_t *r32s, const uint8_t *s32s);
+int zk_prove_batch_collect(zk_prover *p, zk_proof *out, uint32_t count);
 
 /* Multi-GPU split of prove(): steps 1-10 (src/groth16.cpp:52-204) on this prover's shard ... */
 int zk_prove_msm_dev(zk_prover *p, const void *d_wtns, zk_msm_sums *partial);

@@ -33,6 +33,11 @@ struct HostTail {
                                    const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
                                    const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
                                    const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
+    static int finish_from_records(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                                   const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                                   const uint8_t *wa, const uint8_t *wb1, const uint8_t *wc, const uint8_t *wh, const uint8_t *wb2,
+                                   uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
+                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
     // canonical base-10 of a 32-byte LE integer
     static std::string to_dec(const uint8_t le32[32]);
     // de-Montgomery an Fq element and print base-10 (E.f1.toString, src/groth16.cpp:274)

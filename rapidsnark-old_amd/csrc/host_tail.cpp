@@ -306,28 +306,38 @@ int HostTail::finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_
                                   const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
                                   const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
+    const size_t M1 = (size_t)Ww * rcw * sizeof(G1P);      // one MSM's records
+    return finish_from_records(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, w1, w1 + M1, w1 + 2 * M1, w1 + 3 * M1, w2,
+                               Ww, cw, rcw, Wh, ch, rch, r32, s32, outA, outB, outC);
+}
+
+// the same with the five MSMs' records given one by one (a batched submission keeps one bucket set per proof)
+int HostTail::finish_from_records(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                                  const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
+                                  const uint8_t *wa, const uint8_t *wb1, const uint8_t *wc, const uint8_t *wh, const uint8_t *wb2,
+                                  uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
+                                  const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
     uint8_t r[32], s[32];
     if (r32) memcpy(r, r32, 32); else if (draw31(r)) return 1;
     if (s32) memcpy(s, s32, 32); else if (draw31(s)) return 1;
-    const size_t M1 = (size_t)Ww * rcw * sizeof(G1P);      // one MSM's records
     G1P a, b1, c, h;
     G2P b2;
     if (Ww > 1 || Wh > 1) {            // plain tables: five Horner chains of W*c doublings, one host thread each
-        std::thread t1([&] { a = horner<G1P>(w1, Ww, cw, rcw); });
-        std::thread t2([&] { b1 = horner<G1P>(w1 + M1, Ww, cw, rcw); });
-        std::thread t3([&] { c = horner<G1P>(w1 + 2 * M1, Ww, cw, rcw); });
-        std::thread t4([&] { h = horner<G1P>(w1 + 3 * M1, Wh, ch, rch); });
-        b2 = horner<G2P>(w2, Ww, cw, rcw);
+        std::thread t1([&] { a = horner<G1P>(wa, Ww, cw, rcw); });
+        std::thread t2([&] { b1 = horner<G1P>(wb1, Ww, cw, rcw); });
+        std::thread t3([&] { c = horner<G1P>(wc, Ww, cw, rcw); });
+        std::thread t4([&] { h = horner<G1P>(wh, Wh, ch, rch); });
+        b2 = horner<G2P>(wb2, Ww, cw, rcw);
         t1.join();
         t2.join();
         t3.join();
         t4.join();
     } else {
-        a = horner<G1P>(w1, Ww, cw, rcw);
-        b1 = horner<G1P>(w1 + M1, Ww, cw, rcw);
-        c = horner<G1P>(w1 + 2 * M1, Ww, cw, rcw);
-        h = horner<G1P>(w1 + 3 * M1, Wh, ch, rch);
-        b2 = horner<G2P>(w2, Ww, cw, rcw);
+        a = horner<G1P>(wa, Ww, cw, rcw);
+        b1 = horner<G1P>(wb1, Ww, cw, rcw);
+        c = horner<G1P>(wc, Ww, cw, rcw);
+        h = horner<G1P>(wh, Wh, ch, rch);
+        b2 = horner<G2P>(wb2, Ww, cw, rcw);
     }
     assemble_core(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, h, a, b1, b2, c, r, s, outA, outB, outC);
     return 0;

@@ -28,7 +28,7 @@ namespace zk {
 #define REDUCE_CHUNK 16u
 #define REDUCE_THREADS 256u
 
-MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp) {
+MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp, uint32_t batch) {
     MsmPlan p;
     uint32_t lg = 0;
     while ((1ull << (lg + 1)) <= n) lg++;
@@ -51,6 +51,14 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp) {
     p.nbuckets = 1u << (c - 1);
     p.precomp = precomp ? 1u : 0u;
     p.sets = precomp ? 1u : p.W;
+    p.batch = 1;
+    p.batch_n = 0;
+    if (batch > 1) {
+        if (!precomp) throw std::invalid_argument("batched MSMs need window-precomputed tables");
+        p.batch = batch;
+        p.batch_n = (uint32_t)n;
+        p.sets = batch;
+    }
     return p;
 }
 
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *
     const uint32_t set_stride = p.precomp ? 0u : p.nbuckets;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
         Fr s = load_el(scalars + i);
+        const uint32_t vec_base = p.batch > 1 ? (uint32_t)(i / p.batch_n) * p.nbuckets : 0u;      // bucket set of this scalar's vector
         // any 256-bit value is < 6r: bring it below r (never loops for well-formed inputs)
         for (int k = 0; k < 6; k++) {
             Fr d;
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *
             const bool neg = d >= half;                  // digits in [-2^(c-1), 2^(c-1) - 1]
             carry = neg ? 1u : 0u;
             uint32_t mag = neg ? (1u << c) - d : d;      // 0 when raw = 2^c - 1 and carry = 1
-            uint32_t code = mag ? ((mag - 1u + w * set_stride) | (neg ? 0x80000000u : 0u)) : CODE32_ZERO;
+            uint32_t code = mag ? ((mag - 1u + w * set_stride + vec_base) | (neg ? 0x80000000u : 0u)) : CODE32_ZERO;
             digits[(uint64_t)w * n + i] = code;
             w++;
         };
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_count(uint32_t *bin_counts
 #define BIN_ITEMS 8u           // items per thread; span = BIN_ITEMS * SORT_THREADS
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint32_t *val, const uint32_t *bin_starts, const uint32_t *codes,
                                                               uint64_t total, uint32_t nbins, uint32_t nblocks, uint32_t shift, uint32_t span, uint64_t n,
-                                                              uint32_t set_shift) {
+                                                              uint32_t set_shift, uint32_t batch_n) {
     extern __shared__ uint32_t smem[];
     uint32_t *cnt = smem;                         // [BIN_MAX] per-bin count, then LDS start
     uint32_t *gdelta = smem + BIN_MAX;            // [BIN_MAX] global start - LDS start
@@ -363,6 +372,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint
             // table row: the flattened index j*n + i itself with window-precomputed tables
             // (set_shift = 32), the point index i otherwise (key >> set_shift = window j)
             uint64_t i = base + (uint64_t)k * SORT_THREADS + tid - (uint64_t)(set_shift < 32 ? mag >> set_shift : 0u) * n;
+            if (batch_n) {          // batched vectors share the table: flattened j * n + (v * batch_n + r)  ->  row j * batch_n + r
+                const uint64_t j = i / n, r = (i % n) % batch_n;
+                i = j * batch_n + r;
+            }
             st_dst[slot] = slot + gdelta[bin];
             st_val[slot] = (uint32_t)i | (code[k] & 0x80000000u);
             st_lo[slot] = (uint16_t)(mag & lomask);
@@ -1074,7 +1087,7 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
     hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span());
     launch_scan(b.bin_starts, b.bin_counts, nbins * nblocks, s);
     hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), bin_scatter_lds_bytes(), s, b.lo, b.val, (const uint32_t *)b.bin_starts,
-                       (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span(), n, set_shift);
+                       (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span(), n, set_shift, p.batch > 1 ? p.batch_n : 0u);
     hipLaunchKernelGGL(k_bin_count_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
                        (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
     launch_scan(b.starts, b.counts, tb * slices, s);

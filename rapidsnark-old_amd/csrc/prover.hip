@@ -139,9 +139,10 @@ struct SortBufs {
     DevBuf<uint32_t> counts, starts, offsets, entries, codes, val, bin_counts, bin_starts;
     uint32_t total_buckets() const { return plan.sets * plan.nbuckets; }
     uint64_t max_entries() const { return (n ? n : 1) * plan.W; }
-    void alloc(uint64_t n_, uint32_t window_bits, bool precomp = false) {
-        n = n_;
-        plan = make_msm_plan(n ? n : 1, window_bits, precomp);
+    // batch > 1: `batch` scalar vectors of n_ scalars each, sorted together into one bucket set per vector
+    void alloc(uint64_t n_, uint32_t window_bits, bool precomp = false, uint32_t batch = 1) {
+        plan = make_msm_plan(n_ ? n_ : 1, window_bits, precomp, batch);
+        n = n_ * (batch > 1 ? batch : 1);
         // sort entries are 32-bit (bit 31 = digit sign): positions n*W and, with window-precomputed
         // tables, table rows j*n + i must stay below 2^32 / 2^31
         if ((n ? n : 1) * plan.W >= (1ull << 32)) throw std::invalid_argument("MSM too large: n * windows >= 2^32 sort entries");
@@ -227,13 +228,14 @@ struct zk_prover {
         // host-witness proofs (zk_prove / zk_prove_submit): the witness of THIS proof in HBM, and the
         // pinned staging copy a pageable caller buffer goes through.  One per slot, so that proof
         // k+1's upload runs (on its own stream) while proof k is still computing.
-        DevBuf<Fr> wtns_dev;
+        DevBuf<Fr> wtns_dev;              // batch x nVars
         uint8_t *wtns_pin = nullptr;
-        StageJob stage{nullptr, nullptr, 0};
+        StageJob stage[ZK_MAX_BATCH];
         hipEvent_t ev_h2d = nullptr, ev_h2d_start = nullptr;
-        uint8_t r32[32], s32[32];
+        uint8_t r32[ZK_MAX_BATCH][32], s32[ZK_MAX_BATCH][32];
         bool have_r = false, have_s = false;
         bool host_witness = false;
+        uint32_t count = 1;               // proofs this submission carries (<= the prover's batch)
         // small circuits: the ~60 launches of a proof captured once as a HIP graph (per slot: every pointer in it
         // is the slot's or the lane's) and replayed; valid for the witness address it was captured with
         hipGraph_t graph = nullptr;
@@ -258,6 +260,7 @@ struct zk_prover {
     };
     ProofSlot slot[ZK_MAX_IN_FLIGHT];
     uint32_t next_submit = 0, next_collect = 0, in_flight = 0;
+    uint32_t batch = 1;         // opts.batch: witnesses proved by one submission (one set of kernel launches)
     // Small circuits: a proof is ~60 launches of kernels that each fill a tenth of the chip and wait on a
     // serial chain of point additions, so throughput comes from running SEVERAL PROOFS' kernels at once.
     // Consecutive proofs on the same streams cannot (stream order); `lanes` independent sets of
@@ -367,7 +370,7 @@ static void alloc_slot(zk_prover *p, int i) {
     zk_prover::ProofSlot &q = p->slot[i];
     if (q.allocated) return;
     const uint64_t nv = p->sv.size();
-    q.sort_w.alloc(nv, p->wbits, p->precomp);
+    q.sort_w.alloc(nv, p->wbits, p->precomp, p->batch);
     const MsmPlan pw = q.sort_w.plan, ph = p->sort_h.plan;
     const uint64_t tbw = q.sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
     q.buckets_g1.alloc(3 * tbw + tbh);
@@ -428,6 +431,10 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->flags = o ? o->flags : 0;
     p->shard_count = (o && o->shard_count > 1) ? o->shard_count : 1;
     p->shard_index = o ? o->shard_index : 0;
+    p->batch = (o && o->batch > 1) ? o->batch : 1;
+    if (p->batch > ZK_MAX_BATCH) throw std::invalid_argument("opts.batch > ZK_MAX_BATCH");
+    if (p->batch > 1 && (!(p->flags & ZK_FLAG_PRECOMP) || p->shard_count != 1 || (p->flags & ZK_FLAG_PARTITIONED_CHAIN)))
+        throw std::invalid_argument("opts.batch needs ZK_FLAG_PRECOMP on an unsharded prover");
     if (p->shard_index >= p->shard_count) throw std::invalid_argument("shard_index >= shard_count");
     const uint32_t wbits = o ? o->window_bits : 0;
 
@@ -563,7 +570,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     // --- point tables: this shard's contiguous slices
     const uint64_t nv = p->sv.size(), nh = p->sh.size();
     p->precomp = (p->flags & ZK_FLAG_PRECOMP) != 0;
-    p->sort_h.alloc(nh, wbits, p->precomp);
+    p->sort_h.alloc(nh, wbits, p->precomp, p->batch);
     alloc_slot(p.get(), 0);
     // with window pre-computation a table holds W rows: row j = 2^(c*j) * P (msm.hip)
     const uint64_t rows_w = p->precomp ? p->slot[0].sort_w.plan.W : 1, rows_h = p->precomp ? p->sort_h.plan.W : 1;
@@ -621,8 +628,8 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     }
 
     // --- workspace (slot 0 was allocated above; slot 1 appears with the first overlapped submit)
-    p->abc.alloc(3 * p->nloc);
-    p->h.alloc(p->nloc);
+    p->abc.alloc(3 * p->nloc * p->batch);
+    p->h.alloc(p->nloc * p->batch);
     if (p->part) p->xb.alloc(3 * p->nloc);
     p->abc_use = p->abc.p;
     p->xb_use = p->xb.p;
@@ -640,14 +647,14 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             const bool one_stream = ls && atoi(ls) == 1;
             if (one_stream) x->stream2 = x->stream;
             else HIP_TRY(hipStreamCreateWithFlags(&x->stream2, hipStreamNonBlocking));
-            x->abc.alloc(3 * p->nloc);
-            x->h.alloc(p->nloc);
-            x->sort_h.alloc(nh, wbits, p->precomp);
+            x->abc.alloc(3 * p->nloc * p->batch);
+            x->h.alloc(p->nloc * p->batch);
+            x->sort_h.alloc(nh, wbits, p->precomp, p->batch);
             p->extra[l - 1] = std::move(x);
         }
         p->lanes = lanes;
         const char *ge = getenv("ZKHIP_GRAPH");
-        p->use_graph = ge && atoi(ge) != 0 && !p->part && !(p->flags & ZK_FLAG_TIMINGS) && !getenv("ZKHIP_SERIAL");
+        p->use_graph = ge && atoi(ge) != 0 && !p->part && p->batch == 1 && !(p->flags & ZK_FLAG_TIMINGS) && !getenv("ZKHIP_SERIAL");
     }
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
     clk.lap(p->precomp ? "window pre-computation" : "finish", s);
@@ -672,33 +679,48 @@ static void stage_job_run(void *arg) {
     memcpy(j->dst, j->src, per < j->bytes ? per : j->bytes);
     for (auto &t : th) t.join();
 }
-static const Fr *upload_witness(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *h_wtns, hipEvent_t src_ready = nullptr) {
+// `count` host witnesses (count <= the prover's batch) -> consecutive nVars-element vectors of the slot's buffer; the
+// vectors of a batch that are not used are zeroed (an all-zero witness has no non-zero digit: it costs nothing in
+// the MSMs).  d_src (batch provers fed a device pointer): vector 0 is copied from device memory instead.
+static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *const *h_wtns, uint32_t count,
+                                  hipEvent_t src_ready = nullptr, const Fr *d_src = nullptr) {
     const size_t bytes = (size_t)p->nVars * 32;
-    if (!q.wtns_dev.p) q.wtns_dev.alloc(p->nVars);
+    if (!q.wtns_dev.p) q.wtns_dev.alloc((uint64_t)p->nVars * p->batch);
     if (!q.ev_h2d) {
         HIP_TRY(hipEventCreateWithFlags(&q.ev_h2d, hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&q.ev_h2d_start));
     }
-    hipPointerAttribute_t attr;
-    bool pinned = hipPointerGetAttributes(&attr, h_wtns) == hipSuccess && attr.type == hipMemoryTypeHost;
-    (void)hipGetLastError();                       // an unregistered pointer is reported as an error: not one
-    const uint8_t *src = h_wtns;
     hipStream_t sh = p->stream_h2d;
     if (src_ready) HIP_TRY(hipStreamWaitEvent(sh, src_ready, 0));      // the (pinned) source is still being filled
-    if (!pinned) {
-        if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes, hipHostMallocDefault));
-        q.stage = StageJob{q.wtns_pin, h_wtns, bytes};
-        static const bool sync_stage = getenv("ZKHIP_STAGE_SYNC") != nullptr;      // tuning aid: stage inside the call
-        if (sync_stage) stage_job_run(&q.stage);
-        else HIP_TRY(hipLaunchHostFunc(sh, stage_job_run, &q.stage));
-        src = q.wtns_pin;
-    }
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
     if (tm) HIP_TRY(hipEventRecord(q.ev_h2d_start, sh));
-    HIP_TRY(hipMemcpyAsync(q.wtns_dev.p, src, bytes, hipMemcpyHostToDevice, sh));
+    for (uint32_t k = 0; k < count; k++) {
+        uint8_t *dst = (uint8_t *)q.wtns_dev.p + (size_t)k * bytes;
+        if (d_src) {
+            HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToDevice, sh));
+            continue;
+        }
+        hipPointerAttribute_t attr;
+        const bool pinned = hipPointerGetAttributes(&attr, h_wtns[k]) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError();                       // an unregistered pointer is reported as an error: not one
+        const uint8_t *src = h_wtns[k];
+        if (!pinned) {
+            if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes * p->batch, hipHostMallocDefault));
+            q.stage[k] = StageJob{q.wtns_pin + (size_t)k * bytes, h_wtns[k], bytes};
+            static const bool sync_stage = getenv("ZKHIP_STAGE_SYNC") != nullptr;      // tuning aid: stage inside the call
+            if (sync_stage) stage_job_run(&q.stage[k]);
+            else HIP_TRY(hipLaunchHostFunc(sh, stage_job_run, &q.stage[k]));
+            src = q.stage[k].dst;
+        }
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sh));
+    }
+    if (count < p->batch) HIP_TRY(hipMemsetAsync((uint8_t *)q.wtns_dev.p + (size_t)count * bytes, 0, (size_t)(p->batch - count) * bytes, sh));
     HIP_TRY(hipEventRecord(q.ev_h2d, sh));
     if (tm) HIP_TRY(hipEventRecord(q.ev[12], sh));
     return q.wtns_dev.p;
+}
+static const Fr *upload_witness(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *h_wtns, hipEvent_t src_ready = nullptr) {
+    return upload_witnesses(p, q, &h_wtns, 1, src_ready);
 }
 
 // Steps 1-10 of prove() (src/groth16.cpp:52-204), device part: everything is enqueued, nothing waits.
@@ -751,7 +773,15 @@ struct PhaseCtx {
     NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
 };
 
-int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32, hipEvent_t src_ready = nullptr) {
+// several witnesses for one submission of a batch prover (r32s / s32s: count x 32 bytes, or NULL = drawn at collect)
+struct BatchIn {
+    const uint8_t *const *wtns;
+    uint32_t count;
+    const uint8_t *r32s, *s32s;
+};
+
+int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32, hipEvent_t src_ready = nullptr,
+                const BatchIn *bi = nullptr) {
     DeviceGuard g(p->device);
     if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("too many proofs in flight (ZK_MAX_IN_FLIGHT): collect one first");
     if (p->phase_open >= 0) throw std::invalid_argument("a proof is still being submitted phase by phase");
@@ -759,13 +789,26 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     alloc_slot(p, si);
     PhaseCtx c(p, si);
     zk_prover::ProofSlot &q = c.q;
-    const bool staged = h_wtns != nullptr;
-    if (staged) d_wtns = upload_witness(p, q, h_wtns, src_ready);
-    q.host_witness = staged;
+    bool staged = h_wtns != nullptr;
+    q.count = 1;
+    if (bi) {
+        if (bi->count < 1 || bi->count > p->batch) throw std::invalid_argument("batch submission: between 1 and opts.batch witnesses");
+        d_wtns = upload_witnesses(p, q, bi->wtns, bi->count, src_ready);
+        staged = true;
+        q.count = bi->count;
+        r32 = bi->r32s;
+        s32 = bi->s32s;
+    } else if (staged) {
+        d_wtns = upload_witness(p, q, h_wtns, src_ready);
+    } else if (p->batch > 1) {             // a device witness on a batch prover: vector 0 of the slot's buffer, the rest zero
+        d_wtns = upload_witnesses(p, q, nullptr, 1, src_ready, d_wtns);
+        staged = true;
+    }
+    q.host_witness = h_wtns != nullptr || bi != nullptr;
     q.have_r = r32 != nullptr;
     q.have_s = s32 != nullptr;
-    if (r32) memcpy(q.r32, r32, 32);
-    if (s32) memcpy(q.s32, s32, 32);
+    if (r32) memcpy(q.r32, r32, (size_t)32 * q.count);
+    if (s32) memcpy(q.s32, s32, (size_t)32 * q.count);
     hipStream_t s = c.s, s2 = c.s2;
     const bool tails = c.ntails != 0;
     const bool tm = c.tm;
@@ -829,7 +872,8 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     const uint64_t nl = p->nloc;
     Fr *abc = c.abc;
     CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
-    launch_spmv_abc(abc, abc + nl, abc + 2 * nl, csr, d_wtns, (uint32_t)nl, s);
+    for (uint32_t v = 0; v < q.count; v++)         // (a batch: vector v's a|b|c behind vector v-1's; unused vectors are skipped)
+        launch_spmv_abc(abc + 3 * nl * v, abc + 3 * nl * v + nl, abc + 3 * nl * v + 2 * nl, csr, d_wtns + (uint64_t)p->nVars * v, (uint32_t)nl, s);
     c.mark(1);
     if (p->part && !p->have_peers && p->pk_use) launch_chunk_pack(p->pk_use, abc, 3, p->logn, p->log_shards, s);   // -> all_to_all #1
     p->phase_open = si;
@@ -876,8 +920,8 @@ void phase_local(zk_prover *p) {
     NttTables tb = c.tables();
     const bool a2a = p->part && !p->have_peers;          // blocks travel through the caller's all_to_all
     if (a2a) launch_chunk_unpack(c.abc, p->pk_use, 3, p->logn, p->log_shards, c.s);
-    launch_ntt_dif_inverse(c.abc, nl, 3, tb, c.s, local_logn);
-    launch_ntt_dit_forward(c.abc, nl, 3, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
+    launch_ntt_dif_inverse(c.abc, nl, 3 * c.q.count, tb, c.s, local_logn);
+    launch_ntt_dit_forward(c.abc, nl, 3 * c.q.count, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
     if (a2a) launch_chunk_pack(p->pk_use, c.abc, 3, p->logn, p->log_shards, c.s);
     p->phase_next = p->part ? 3 : 4;
 }
@@ -892,7 +936,9 @@ void phase_back(zk_prover *p) {
     Fr *abc = c.abc;
     if (p->part && !p->have_peers) launch_chunk_unpack(abc, p->pk_use, 3, p->logn, p->log_shards, s);
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
-    launch_abc_to_h(c.h, abc, abc + nl, abc + 2 * nl, nl, s);
+    for (uint32_t v = 0; v < q.count; v++)
+        launch_abc_to_h(c.h + nl * v, abc + 3 * nl * v, abc + 3 * nl * v + nl, abc + 3 * nl * v + 2 * nl, nl, s);
+    if (q.count < p->batch) HIP_TRY(hipMemsetAsync(c.h + nl * q.count, 0, (size_t)(p->batch - q.count) * nl * sizeof(Fr), s));    // h of an unused vector: no digits
     c.mark(2);
     c.sort_h->run(c.h + (p->part ? 0 : p->sh.lo), s);
     c.mark(3);
@@ -998,7 +1044,7 @@ static void submit_graph(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, 
     p->in_flight++;
 }
 
-static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
+static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32, const BatchIn *bi = nullptr) {
     if (p->part) throw std::invalid_argument("this prover holds one block of a partitioned chain: drive it through zk_multi_prove* or zk_shard_*");
     DeviceGuard g(p->device);
     if (p->use_graph) {
@@ -1006,7 +1052,7 @@ static void submit_locked(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns,
         return;
     }
     PhaseAbort guard{p};
-    phase_front(p, d_wtns, h_wtns, r32, s32);
+    phase_front(p, d_wtns, h_wtns, r32, s32, nullptr, bi);
     phase_local(p);
     phase_back(p);
     guard.armed = false;
@@ -1022,9 +1068,10 @@ struct SubmittedRS {
 // `direct` (unsharded provers): assemble the proof straight from the window sums instead of filling `out`;
 // (r32, s32) given by the caller override the ones captured at submit (synchronous zk_prove).
 struct DirectProof {
-    zk_proof *out;
+    zk_proof *out;              // `count` proofs (1 unless the submission was a batch)
     const uint8_t *r32, *s32;
     bool use_submitted;
+    uint32_t count = 1;
 };
 static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullptr, const DirectProof *direct = nullptr) {
     std::lock_guard<std::mutex> ck(p->cmtx);
@@ -1053,8 +1100,8 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     if (rs) {
         rs->have_r = q.have_r;
         rs->have_s = q.have_s;
-        memcpy(rs->r32, q.r32, 32);
-        memcpy(rs->s32, q.s32, 32);
+        memcpy(rs->r32, q.r32[0], 32);
+        memcpy(rs->s32, q.s32[0], 32);
     }
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
     if (tm) {
@@ -1087,9 +1134,24 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     const uint32_t cw = q.sort_w.plan.c, ch = p->sort_h.plan.c;
     const size_t P1 = sizeof(G1XYZZ);
     const uint8_t *w1 = q.w1, *w2 = q.w2;
+    if (direct && p->batch > 1) {
+        // one bucket set per proof of the submission: records [msm][proof][rc]
+        if (direct->count != q.count) throw std::invalid_argument("this submission carries a different number of proofs");
+        const size_t Rw = (size_t)rcw * sizeof(G1XYZZ), Rh = (size_t)rch * sizeof(G1XYZZ), R2 = (size_t)rcw * sizeof(G2XYZZ);
+        for (uint32_t k = 0; k < q.count; k++) {
+            const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[k] : nullptr) : direct->r32;
+            const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[k] : nullptr) : direct->s32;
+            if (HostTail::finish_from_records(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2,
+                                              w1 + k * Rw, w1 + M1 + k * Rw, w1 + 2 * M1 + k * Rw, w1 + 3 * M1 + k * Rh, w2 + k * R2,
+                                              1, cw, rcw, 1, ch, rch, r32, s32, direct->out[k].A, direct->out[k].B, direct->out[k].C))
+                throw std::runtime_error("getrandom failed");
+        }
+        return;
+    }
+    if (p->batch > 1) throw std::invalid_argument("partial sums are not available from a batch prover");
     if (direct) {
-        const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32 : nullptr) : direct->r32;
-        const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32 : nullptr) : direct->s32;
+        const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[0] : nullptr) : direct->r32;
+        const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[0] : nullptr) : direct->s32;
         if (HostTail::finish_from_windows(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, w1, w2, Ww, cw, rcw, Wh, ch, rch,
                                           r32, s32, direct->out->A, direct->out->B, direct->out->C))
             throw std::runtime_error("getrandom failed");
@@ -1238,6 +1300,34 @@ int zk_prove_collect(zk_prover *p, zk_proof *out) {
         if (!p || !out) throw std::invalid_argument("null argument");
         if (p->shard_count != 1) throw std::invalid_argument("zk_prove_collect on a sharded prover: use zk_prove_msm_collect + zk_prove_finish");
         const DirectProof d{out, nullptr, nullptr, true};
+        collect_sums(p, nullptr, nullptr, &d);
+    });
+}
+
+int zk_prove_batch_submit(zk_prover *p, const uint8_t *const *wtns, uint32_t count, const uint8_t *r32s, const uint8_t *s32s) {
+    return guarded([&] {
+        if (!p || !wtns || !count) throw std::invalid_argument("null argument");
+        for (uint32_t k = 0; k < count; k++)
+            if (!wtns[k]) throw std::invalid_argument("null witness pointer");
+        if (p->shard_count != 1) throw std::invalid_argument("zk_prove_batch_submit on a sharded prover");
+        if (count > p->batch) throw std::invalid_argument("more witnesses than the prover's opts.batch");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        if (p->batch > 1) {
+            const BatchIn bi{wtns, count, r32s, s32s};
+            submit_locked(p, nullptr, nullptr, nullptr, nullptr, &bi);
+        } else {
+            submit_locked(p, nullptr, wtns[0], r32s, s32s);
+        }
+    });
+}
+
+int zk_prove_batch_collect(zk_prover *p, zk_proof *out, uint32_t count) {
+    return guarded([&] {
+        if (!p || !out || !count) throw std::invalid_argument("null argument");
+        if (p->shard_count != 1) throw std::invalid_argument("zk_prove_batch_collect on a sharded prover");
+        DirectProof d{out, nullptr, nullptr, true};
+        d.count = count;
+        if (p->batch == 1 && count != 1) throw std::invalid_argument("this prover was not created with opts.batch");
         collect_sums(p, nullptr, nullptr, &d);
     });
 }

@@ -93,11 +93,19 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
         const uint64_t sizes[6] = {zkey->getSectionSize(4), zkey->getSectionSize(5), zkey->getSectionSize(6),
                                    zkey->getSectionSize(7), zkey->getSectionSize(8), zkey->getSectionSize(9)};
         Circuit &c = circuits[circuit];
+        // throughput mode, small circuits: a submission carries up to `batch` witnesses (one set of kernel launches:
+        // a 2^14 proof is ~60 latency-bound kernels, four proofs in them cost little more than one).  ZKHIP_BATCH=n
+        // (0/1 = off, at most ZK_MAX_BATCH) overrides the default of 4 up to 2^17 constraints.
+        uint32_t batch = 0;
+        if (queueMode()) {
+            const char *be = getenv("ZKHIP_BATCH");
+            batch = be ? (uint32_t)strtoul(be, nullptr, 10) : (hdr->domainSize <= (1u << 17) ? 4u : 0u);
+        }
         for (int dev : workerDevices)
             c.replica.push_back(Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
                                                     hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
                                                     zkey->getSectionData(5), zkey->getSectionData(6), zkey->getSectionData(7),
-                                                    zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true, dev));
+                                                    zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true, dev, batch));
         // libzkhip copied everything it needs to the GPU: only the scalar header fields are kept
         // (the vk pointers into the mapping die with `zkey` and are never used again here)
         hdr->vk_alpha1 = hdr->vk_beta1 = hdr->vk_beta2 = hdr->vk_gamma2 = hdr->vk_delta1 = hdr->vk_delta2 = nullptr;
@@ -307,7 +315,7 @@ void FullProver::witnessLoop() {
 void FullProver::deviceLoop(size_t worker) {
     std::mutex wm;
     std::condition_variable cv;
-    std::deque<JobPtr> fifo;                       // submitted, not yet collected (submission order)
+    std::deque<std::vector<JobPtr>> fifo;          // submissions (one or, on a batch replica, several jobs) not yet collected
     std::map<std::string, size_t> perCircuit;
     bool submitterDone = false;
     uint8_t r[32], s[32];
@@ -315,30 +323,39 @@ void FullProver::deviceLoop(size_t worker) {
 
     std::thread collector([&] {
         for (;;) {
-            JobPtr job;
+            std::vector<JobPtr> jobs;
             {
                 std::unique_lock<std::mutex> lk(wm);
                 cv.wait(lk, [&] { return submitterDone || !fifo.empty(); });
                 if (fifo.empty()) return;
-                job = fifo.front();
+                jobs = fifo.front();
             }
-            std::string proofJson, error;
+            std::vector<std::string> proofJson(jobs.size());
+            std::string error;
             try {
-                proofJson = circuits[job->circuit].replica[worker]->collect()->toJson();
+                Groth16::Prover &pr = *circuits[jobs[0]->circuit].replica[worker];
+                if (jobs.size() == 1 && pr.batch() == 1) {
+                    proofJson[0] = pr.collect()->toJson();
+                } else {
+                    auto proofs = pr.collectBatch((uint32_t)jobs.size());
+                    for (size_t k = 0; k < jobs.size(); k++) proofJson[k] = proofs[k]->toJson();
+                }
             } catch (std::exception &e) {
                 error = e.what();
             }
             {
                 std::lock_guard<std::mutex> guard(mtx);
-                job->wtns.reset();
-                job->proof = error.empty() ? proofJson : "null";
-                job->error = error;
-                job->status = error.empty() ? success : failed;
+                for (size_t k = 0; k < jobs.size(); k++) {
+                    jobs[k]->wtns.reset();
+                    jobs[k]->proof = error.empty() ? proofJson[k] : "null";
+                    jobs[k]->error = error;
+                    jobs[k]->status = error.empty() ? success : failed;
+                }
             }
             {
                 std::lock_guard<std::mutex> lk(wm);
                 fifo.pop_front();
-                perCircuit[job->circuit]--;
+                perCircuit[jobs[0]->circuit]--;
             }
             cv.notify_all();
         }
@@ -346,12 +363,14 @@ void FullProver::deviceLoop(size_t worker) {
 
     for (;;) {
         JobPtr job;
+        std::vector<JobPtr> jobs;
         {
             std::unique_lock<std::mutex> lk(mtx);
             cvReady.wait(lk, [&] { return stopping || !readyJobs.empty(); });
             if (stopping) break;
             job = readyJobs.front();
             readyJobs.pop_front();
+            jobs.push_back(job);
         }
         // depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs GiBs of
         // workspace); small circuits are latency-bound per proof and want the maximum
@@ -360,19 +379,41 @@ void FullProver::deviceLoop(size_t worker) {
             std::unique_lock<std::mutex> lk(wm);
             cv.wait(lk, [&] { return perCircuit[job->circuit] < depth; });
         }
+        {
+            // a batch replica: whatever else is READY NOW for the same circuit rides along (it never waits for more)
+            std::lock_guard<std::mutex> lk(mtx);
+            const uint32_t cap = circuits[job->circuit].replica[worker]->batch();
+            for (auto it = readyJobs.begin(); it != readyJobs.end() && jobs.size() < cap;) {
+                if ((*it)->circuit == job->circuit) {
+                    jobs.push_back(*it);
+                    it = readyJobs.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
         try {
-            circuits[job->circuit].replica[worker]->submit(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr);
+            Groth16::Prover &pr = *circuits[job->circuit].replica[worker];
+            if (pr.batch() == 1) {
+                pr.submit(job->wtnsData, haveR ? r : nullptr, haveS ? s : nullptr);
+            } else {
+                std::vector<const void *> ws;
+                for (auto &j : jobs) ws.push_back(j->wtnsData);
+                pr.submitBatch(ws, haveR ? r : nullptr, haveS ? s : nullptr);
+            }
             {
                 std::lock_guard<std::mutex> lk(wm);
-                fifo.push_back(job);
+                fifo.push_back(jobs);
                 perCircuit[job->circuit]++;
             }
             cv.notify_all();
         } catch (std::exception &e) {
             std::lock_guard<std::mutex> guard(mtx);
-            job->wtns.reset();
-            job->error = e.what();
-            job->status = failed;
+            for (auto &j : jobs) {
+                j->wtns.reset();
+                j->error = e.what();
+                j->status = failed;
+            }
         }
     }
     {

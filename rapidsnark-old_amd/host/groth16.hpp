@@ -31,9 +31,10 @@ public:
 class Prover {
     zk_prover *h_ = nullptr;
     zk_multi_prover *m_ = nullptr;      // ZKHIP_DEVICES=0,1,...: one proof split over several GPUs
+    uint32_t batch_ = 1;                // witnesses one submission may carry (zk_opts.batch)
 
 public:
-    explicit Prover(zk_prover *h) : h_(h) {}
+    explicit Prover(zk_prover *h, uint32_t batch = 1) : h_(h), batch_(batch > 1 ? batch : 1) {}
     explicit Prover(zk_multi_prover *m) : m_(m) {}
     ~Prover() {
         if (h_) zk_prover_destroy(h_);
@@ -62,6 +63,32 @@ public:
         if ((m_ ? zk_multi_prove_collect(m_, &p->raw) : zk_prove_collect(h_, &p->raw)) != 0) throw std::runtime_error(zk_last_error());
         return p;
     }
+    // Small circuits: up to batch() witnesses of the circuit in ONE submission (zk_prove_batch_*): one set of kernel
+    // launches for all of them.  r32 / s32 (optional) are used for every proof of the submission.
+    uint32_t batch() const { return batch_; }
+    void submitBatch(const std::vector<const void *> &wtns, const uint8_t *r32 = nullptr, const uint8_t *s32 = nullptr) {
+        if (wtns.empty() || wtns.size() > batch_) throw std::invalid_argument("submitBatch: between 1 and batch() witnesses");
+        if (m_) throw std::invalid_argument("submitBatch on a multi-GPU prover");
+        std::vector<const uint8_t *> ptrs;
+        std::vector<uint8_t> rr, ss;
+        for (const void *w : wtns) {
+            ptrs.push_back(static_cast<const uint8_t *>(w));
+            if (r32) rr.insert(rr.end(), r32, r32 + 32);
+            if (s32) ss.insert(ss.end(), s32, s32 + 32);
+        }
+        if (zk_prove_batch_submit(h_, ptrs.data(), (uint32_t)ptrs.size(), r32 ? rr.data() : nullptr, s32 ? ss.data() : nullptr) != 0)
+            throw std::runtime_error(zk_last_error());
+    }
+    std::vector<std::unique_ptr<Proof>> collectBatch(uint32_t count) {
+        std::vector<zk_proof> raw(count);
+        if (zk_prove_batch_collect(h_, raw.data(), count) != 0) throw std::runtime_error(zk_last_error());
+        std::vector<std::unique_ptr<Proof>> out;
+        for (uint32_t k = 0; k < count; k++) {
+            out.emplace_back(new Proof());
+            out.back()->raw = raw[k];
+        }
+        return out;
+    }
 };
 
 // "0,1,2,3" -> {0,1,2,3}
@@ -82,7 +109,7 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
                                           void *vk_alpha1, void *vk_beta1, void *vk_beta2, void *vk_delta1, void *vk_delta2,
                                           void *coefs, void *pointsA, void *pointsB1, void *pointsB2, void *pointsC,
                                           void *pointsH, const uint64_t sectionBytes[6] = nullptr, bool precompDefault = false,
-                                          int device = -1) {
+                                          int device = -1, uint32_t batch = 0) {
     zk_zkey_view v{};
     v.nVars = nVars;
     v.nPublic = nPublic;
@@ -127,9 +154,10 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
         }
         if (devs.size() == 1) o.device = devs[0];
     }
+    if (batch > 1 && (o.flags & ZK_FLAG_PRECOMP)) o.batch = batch > ZK_MAX_BATCH ? ZK_MAX_BATCH : batch;
     zk_prover *h = nullptr;
     if (zk_prover_create(&h, &v, &o) != 0) throw std::runtime_error(zk_last_error());
-    return std::unique_ptr<Prover>(new Prover(h));
+    return std::unique_ptr<Prover>(new Prover(h, o.batch));
 }
 
 }   // namespace Groth16

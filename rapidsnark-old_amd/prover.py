@@ -38,14 +38,15 @@ def _zkey_view(zkey, keep):
 
 class Prover:
     def __init__(self, zkey, device=-1, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=False,
-                 partitioned_chain=False):
-        """zkey: path or bytes of a snarkjs .zkey (version <= 1, main_prover.cpp:42)."""
+                 partitioned_chain=False, batch=0):
+        """zkey: path or bytes of a snarkjs .zkey (version <= 1, main_prover.cpp:42).
+        batch >= 2 (with precomp): submit_batch / collect_batch prove up to `batch` witnesses per submission."""
         self._lib = L.load_library()
         self._keep = []
         self.header, v = _zkey_view(zkey, self._keep)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
                       (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
-                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0))
+                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0), batch)
         self._h = C.c_void_p()
         L.check(self._lib.zk_prover_create(C.byref(self._h), C.byref(v), C.byref(o)))
         self._keep = []     # host image may be released after create (include/zkhip.h)
@@ -111,6 +112,32 @@ class Prover:
         (ra, rp), (sa, sp) = self._rs(r), self._rs(s)
         L.check(self._lib.zk_prove_submit(self._h, C.c_void_p(a.ctypes.data), rp, sp))
         self._pending = getattr(self, "_pending", []) + [a]      # the library reads it until the proof is collected
+
+    def submit_batch(self, wtns_list, rs=None):
+        """zk_prove_batch_submit: several witnesses (each as for submit()) in ONE submission of a prover created
+        with batch >= len(wtns_list); rs = list of (r, s) or None."""
+        arrs = [w if isinstance(w, np.ndarray) else self._wtns_values(w) for w in wtns_list]
+        for a in arrs:
+            if a.size != self.header.nVars * 32:
+                raise ValueError("witness size mismatch")
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        rp = sp = None
+        keep = [arrs]
+        if rs is not None:
+            rb = np.frombuffer(b"".join(int(r).to_bytes(32, "little") for r, _ in rs), dtype=np.uint8).copy()
+            sb = np.frombuffer(b"".join(int(s_).to_bytes(32, "little") for _, s_ in rs), dtype=np.uint8).copy()
+            rp, sp = C.c_void_p(rb.ctypes.data), C.c_void_p(sb.ctypes.data)
+            keep += [rb, sb]
+        L.check(self._lib.zk_prove_batch_submit(self._h, ptrs, n, rp, sp))
+        self._pending = getattr(self, "_pending", []) + [keep]
+
+    def collect_batch(self, count):
+        """-> list of `count` proofs of the OLDEST submission (zk_prove_batch_collect)."""
+        out = (L.zk_proof * count)()
+        L.check(self._lib.zk_prove_batch_collect(self._h, out, count))
+        self._pending = getattr(self, "_pending", [])[1:]
+        return [bytes(o) for o in out]
 
     def collect(self):
         """-> proof bytes of the OLDEST submitted proof (zk_prove_collect)."""
