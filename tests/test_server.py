@@ -142,11 +142,14 @@ def _start_server(tmp_path, names, env_extra):
 
 
 @pytest.mark.gpu
-def test_throughput_mode_concurrent_requests_all_golden(tmp_path):
+@pytest.mark.parametrize("batch", ["1", "4", "8"])
+def test_throughput_mode_concurrent_requests_all_golden(tmp_path, batch):
     """BASELINE configs[4] shape: ZKHIP_QUEUE + ZKHIP_WORKERS — many /input requests fired at once, every
     one of them answered with the golden proof of ITS circuit (fixed r, s), none dropped or replaced.
     Two worker replicas share the box's one GPU (ZKHIP_WORKERS=0,0): one dispatcher thread per replica,
-    up to three proofs in flight on each, witness generators running beside them."""
+    up to eight submissions in flight on each, witness generators running beside them; ZKHIP_BATCH: every
+    job that is ready for the same circuit when a dispatcher takes one rides in the same submission
+    (zk_prove_batch_submit), 1 = one job per submission."""
     import concurrent.futures
     names = ["r1cs_n8", "r1cs_n64", "r1cs_n256"]
     meta = golden_json("r1cs_n64", "meta.json")            # the fixtures share (r, s)? no: use each fixture's own below
@@ -160,7 +163,7 @@ def test_throughput_mode_concurrent_requests_all_golden(tmp_path):
         sub = tmp_path / ("g%d" % (hash((r, s)) & 0xffff))
         sub.mkdir()
         srv, port = _start_server(sub, group, {"ZKHIP_FIXED_R": _le_hex(r), "ZKHIP_FIXED_S": _le_hex(s), "ZKHIP_QUEUE": "64",
-                                               "ZKHIP_WORKERS": "0,0", "ZKHIP_WITNESS_THREADS": "3"})
+                                               "ZKHIP_WORKERS": "0,0", "ZKHIP_WITNESS_THREADS": "3", "ZKHIP_BATCH": batch})
         try:
             assert json.loads(_http(port, "GET", "/status")[1]) == {"status": "ready"}
             reqs = [group[i % len(group)] for i in range(24)]
