@@ -62,6 +62,7 @@ def parse():
                     help="1 (default, single GPU): consecutive proofs overlap through zk_prove_dev_submit / zk_prove_collect "
                          "(two in flight); 0: strictly one proof at a time (zk_prove_dev)")
     ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = by size: 3 with host witnesses / 2 with resident ones from 2^19 up, 8 below; max 8)")
+    ap.add_argument("--batch", type=int, default=0, help="N = 1, host witnesses: B >= 2 = B witnesses per submission (zk_prove_batch_submit; small circuits). --steps must be a multiple of B")
     ap.add_argument("--collector-thread", type=int, default=1, help="N = 1: collect on a second host thread (1, default) or in the submitting thread (0)")
     ap.add_argument("--witness-in", choices=["host", "hbm"], default="host",
                     help="host (default): witnesses are pageable host arrays and every upload is timed (the reference's contract); "
@@ -77,6 +78,8 @@ def parse():
 
 def main():
     args = parse()
+    if args.batch > 1 and (args.steps % args.batch or args.gpus != 1):
+        raise SystemExit("--batch B needs --gpus 1 and --steps a multiple of B")
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # six streams per prover (csrc/prover.hip); read when HIP initialises
     import torch
     import rapidsnark_old_amd as zk
@@ -118,7 +121,8 @@ def main():
     if args.chain == "partitioned" and not partitioned:
         raise SystemExit("--chain partitioned needs 2, 4 or 8 ranks")
     prover = ProverFromView(zk, wl, device=local_rank, shard_index=rank, shard_count=world,
-                            window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned)
+                            window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned,
+                            batch=args.batch if world == 1 else 0)
     t_create = time.time() - t0
     chain = None
     sliced_upload = False
@@ -158,8 +162,14 @@ def main():
     def timed_run(in_hbm, steps, warmup):
         """`warmup` untimed + exactly `steps` timed whole proofs, each with its own witness and random
         r,s (like the reference).  -> (seconds, mean stage timings)."""
+        units = args.batch if (args.batch > 1 and world == 1 and not in_hbm) else 1     # proofs per submission
+        nsub = steps // units
+
         def submit(i):
             j = i % len(wits_host)
+            if units > 1:                                    # zk_prove_batch_submit: `units` witnesses, one set of launches
+                prover.submit_batch([wits_host[(i * units + t) % len(wits_host)] for t in range(units)])
+                return
             if chain is not None:                            # phases + four rounds of all_to_all (RCCL over xGMI)
                 if in_hbm:
                     chain.submit(d_wtns=wits_dev[j].data_ptr())
@@ -173,7 +183,9 @@ def main():
                 prover.submit_host(wits_host[j])             # pageable -> pinned staging -> HBM, all inside the call / its stream
 
         def collect():
-            if world == 1:
+            if units > 1:
+                prover.collect_batch(units)
+            elif world == 1:
                 prover.collect()
             else:                                            # this rank's partial sums -> all ranks -> rank 0 assembles
                 parts = zk.gather_partials(prover.collect_msm(), dist, xdev)     # RCCL all_gather over xGMI: 384 B per rank
@@ -219,7 +231,7 @@ def main():
 
                 def collector():
                     try:
-                        for _ in range(steps):
+                        for _ in range(nsub):
                             ready.acquire()               # never ask for a proof that has not been submitted yet
                             if errors:
                                 return
@@ -228,12 +240,12 @@ def main():
                             free.release()
                     except Exception as exc:              # noqa: BLE001
                         errors.append(exc)
-                        for _ in range(steps):
+                        for _ in range(nsub):
                             free.release()
 
                 th = threading.Thread(target=collector)
                 started = False
-                for i in range(steps):
+                for i in range(nsub):
                     free.acquire()
                     if errors:
                         break
@@ -241,7 +253,7 @@ def main():
                         submit(warmup + i)
                     except Exception as exc:              # noqa: BLE001
                         errors.append(exc)
-                        for _ in range(steps):
+                        for _ in range(nsub):
                             ready.release()
                         break
                     ready.release()
@@ -254,7 +266,7 @@ def main():
                     raise errors[0]
             else:
                 flying = 0
-                for i in range(steps):
+                for i in range(nsub):
                     submit(warmup + i)
                     flying += 1
                     if flying == depth:
@@ -266,7 +278,7 @@ def main():
                     add_timings()
                     flying -= 1
         else:
-            for i in range(steps):
+            for i in range(nsub):
                 submit(warmup + i)
                 collect()
                 add_timings()
@@ -278,7 +290,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, {kk: v / steps for kk, v in stage.items()}
+        return dt, {kk: v / nsub for kk, v in stage.items()}
 
     headline_hbm = args.witness_in == "hbm"
     elapsed, stage = timed_run(headline_hbm, args.steps, args.warmup)
@@ -333,6 +345,7 @@ def main():
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
               "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm)) if pipelined else 1,
+              "witnesses_per_submission": args.batch if (args.batch > 1 and world == 1 and not headline_hbm) else 1,
               "host_threads": 2 if (pipelined and world == 1 and args.collector_thread) else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
