@@ -693,10 +693,10 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
     hipStream_t sh = p->stream_h2d;
     if (src_ready) HIP_TRY(hipStreamWaitEvent(sh, src_ready, 0));      // the (pinned) source is still being filled
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
-    if (tm) HIP_TRY(hipEventRecord(q.ev_h2d_start, sh));
     for (uint32_t k = 0; k < count; k++) {
         uint8_t *dst = (uint8_t *)q.wtns_dev.p + (size_t)k * bytes;
         if (d_src) {
+            if (tm && k == 0) HIP_TRY(hipEventRecord(q.ev_h2d_start, sh));
             HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToDevice, sh));
             continue;
         }
@@ -712,6 +712,7 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
             else HIP_TRY(hipLaunchHostFunc(sh, stage_job_run, &q.stage[k]));
             src = q.stage[k].dst;
         }
+        if (tm && k == 0) HIP_TRY(hipEventRecord(q.ev_h2d_start, sh));      // ZK_T_WTNS_H2D: the DMA (of the first vector on), not the staging
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sh));
     }
     if (count < p->batch) HIP_TRY(hipMemsetAsync((uint8_t *)q.wtns_dev.p + (size_t)count * bytes, 0, (size_t)(p->batch - count) * bytes, sh));
