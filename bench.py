@@ -395,8 +395,8 @@ def default_depth(k, in_hbm):
     hidden); below 2^19 a proof is bound by the serial latency of its ~80 small kernels and more in flight fills the GPU."""
     if k < 19:
         return 8
-    if k <= 21:          # four lanes of streams per prover up to 2^21 (csrc/prover.hip): 2^20 11.1 -> 10.2 ms with six
-        return 6 if k <= 20 else 4
+    if k <= 22:          # four lanes of streams per prover up to 2^22 (csrc/prover.hip): 2^20 11.1 -> 10.2 ms with six in
+        return 6 if k <= 20 else 4          # flight; 2^22 with four: the host-witness rate reaches the resident one (36.6 -> 35.6 ms)
     return 2 if in_hbm else 3
 
 

@@ -636,7 +636,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     {
         // lanes for small circuits (see zk_prover::LaneExtra).  ZKHIP_LANES=1..4 overrides.
         const char *e = getenv("ZKHIP_LANES");
-        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 21) ? 4 : 1);
+        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 22) ? 4 : 1);
         if (lanes < 1) lanes = 1;
         if (lanes > zk_prover::MAX_LANES) lanes = zk_prover::MAX_LANES;
         if (p->part || getenv("ZKHIP_SERIAL")) lanes = 1;
