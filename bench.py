@@ -204,7 +204,7 @@ def main():
         if pipelined and warmup:
             # still untimed: fill the pipeline once, so that every proof slot the timed loop uses exists (a slot's
             # buffers are allocated the first time its depth is reached)
-            depth0 = args.in_flight or default_depth(k, in_hbm)
+            depth0 = args.in_flight or default_depth(k, in_hbm, world)
             for i in range(depth0):
                 submit(i)
             for i in range(depth0):
@@ -218,7 +218,7 @@ def main():
             # i is collected, so its sort, SpMV and NTTs overlap proof i's reductions, D2H and host tail;
             # with host witnesses a third proof hides the upload (a proof cannot start before its witness
             # has arrived, and a slot is only free again after a collect)
-            depth = args.in_flight or default_depth(k, in_hbm)
+            depth = args.in_flight or default_depth(k, in_hbm, world)
             if world == 1 and args.collector_thread:
                 # two host threads, as a server would run them: this one submits, the other collects (wait for
                 # the GPU + 0.3 ms of host tail per proof: window sums, final assembly).  The
@@ -344,7 +344,7 @@ def main():
     # accumulation of MSM B2 (160 B per point).
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
-              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm)) if pipelined else 1,
+              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
               "witnesses_per_submission": args.batch if (args.batch > 1 and world == 1 and not headline_hbm) else 1,
               "host_threads": 2 if (pipelined and world == 1 and args.collector_thread) else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
@@ -390,12 +390,12 @@ def main():
         dist.destroy_process_group()
 
 
-def default_depth(k, in_hbm):
+def default_depth(k, in_hbm, world=1):
     """Proofs in flight per GPU: large circuits saturate the chip with two (three when the witness upload has to be
     hidden); below 2^19 a proof is bound by the serial latency of its ~80 small kernels and more in flight fills the GPU."""
     if k < 19:
         return 8
-    if k <= 22:          # four lanes of streams per prover up to 2^22 (csrc/prover.hip): 2^20 11.1 -> 10.2 ms with six in
+    if k <= 22 and world == 1:          # four lanes of streams per prover up to 2^22 (csrc/prover.hip): 2^20 11.1 -> 10.2 ms with six in
         return 6 if k <= 20 else 4          # flight; 2^22 with four: the host-witness rate reaches the resident one (36.6 -> 35.6 ms)
     return 2 if in_hbm else 3
 
