@@ -49,8 +49,8 @@ G2_MSM_BYTES_PER_POINT = 160   # 128 B affine G2 point + 32 B scalar
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=22)
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--witness", choices=["uniform", "realistic"], default="uniform",
