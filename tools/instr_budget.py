@@ -1,8 +1,8 @@
 """VALU instruction budget of one proof from a rocprofv3 --pmc SQ_INSTS_VALU run (ZKHIP_SERIAL=1 recommended).
-    python tools/instr_budget.py <dir> [proofs_profiled=2]"""
+    python tools/instr_budget.py <dir> [proofs_profiled: default = the number of k_spmv_abc launches]"""
 import csv, glob, collections, sys
 d = sys.argv[1]
-nproofs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+nproofs = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0      # 0 = count them: one k_spmv_abc launch per proof
 agg = collections.defaultdict(float); cnt = collections.Counter(); dur = collections.defaultdict(float)
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -13,6 +13,8 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         if 'Fp2T' in n:
             key += ' [G2]'
         agg[key] += float(r['Counter_Value']); cnt[key] += 1
+if nproofs <= 0:
+    nproofs = float(max(1, cnt.get('k_spmv_abc', 1)))
 skip = ('precomp', 'chain', 'build_tables', 'fq_to_internal', 'fr_convert', 'csr', 'fixed_base')
 rows = [(v / nproofs, k, cnt[k] / nproofs) for k, v in agg.items() if not any(x in k for x in skip)]
 tot = sum(v for v, _, _ in rows)

@@ -12,7 +12,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py "$@" > $out/bench.json 2> $out/bench.err
-args="--steps 6 --warmup 2 --no-cpu"   # 8 + 7 + 6 = 21 proofs per profiled run (tools/instr_budget.py divides by it)
+args="--steps 6 --warmup 2 --no-cpu"   # (tools/instr_budget.py counts the proofs itself: one k_spmv_abc launch each)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py $args > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python bench.py $args > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python bench.py $args > $out/write.log 2>&1
@@ -24,5 +24,5 @@ mkdir -p $out/profiles
 python tools/summarize_profiles.py $tag $sd $fd $wd $out/bench.json && cp profiles/${tag}_* $out/profiles/
 cp $out/bench.json $out/profiles/${tag}_bench_2p22.json
 vd=$(find $out/valu -name '*counter_collection.csv' | head -1)
-python tools/instr_budget.py $out/valu 21 > $out/profiles/${tag}_valu_instruction_budget.txt 2>&1 || true
+python tools/instr_budget.py $out/valu > $out/profiles/${tag}_valu_instruction_budget.txt 2>&1 || true
 ls -la $out/profiles
