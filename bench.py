@@ -318,11 +318,14 @@ def main():
             ref.lib.zk_prover_destroy(ref.h)
 
     latency_ms = latency_host_ms = None
+    lone = {}
     if world == 1:                        # outside the timed region: strictly one proof at a time
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(3):
             one_proof(i)
+            for kk, v in prover.timings().items():
+                lone[kk] = lone.get(kk, 0.0) + v / 3
         latency_ms = (time.perf_counter() - t1) / 3 * 1e3
         t1 = time.perf_counter()
         for i in range(3):
@@ -358,6 +361,11 @@ def main():
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launch_ms": round(g1_ms, 4), "launches_per_proof": 4, "algorithmic_bytes": alg_bytes,
+                "launch_sharing": "launch_ms is the mean over the timed region, where a launch shares the chip with the kernels of the other proofs in flight "
+                                  "(config.proofs_in_flight): more in flight raises proofs/s and LOWERS this fraction; launch_ms_one_proof_in_flight is the same "
+                                  "launch with one proof at a time (it still runs beside that proof's own G2 launch), measured after the timed region",
+                "launch_ms_one_proof_in_flight": round(lone["g1_l1_kernel"], 4) if lone else None,
+                "frac_one_proof_in_flight": round(alg_bytes / (lone["g1_l1_kernel"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if lone else None,
                 "also": {"kernel": "k_msm_accum_l1_g2s (G2 bucket accumulation of MSM B2, Fq2 split across lane pairs; the longest single launch)",
                          "launch_ms": round(g2_ms, 4), "algorithmic_bytes": G2_MSM_BYTES_PER_POINT * pts_per_launch,
                          "achieved": round(G2_MSM_BYTES_PER_POINT * pts_per_launch / (g2_ms * 1e-3) / 1e9, 3),
