@@ -108,10 +108,10 @@ int zk_prove_dev(zk_prover *p, const void *d_wtns, const uint8_t *r32, const uin
  * (bucket reductions, D2H, host Horner + final assembly, src/groth16.cpp:219-251).
  * zk_prove_dev_submit enqueues all device work of one proof and returns; at most ZK_MAX_IN_FLIGHT
  * proofs may be in flight per prover; per-proof buffers are allocated the first time a depth is reached.
- * Large circuits: two keep the chip busy when witnesses are resident in HBM, a third hides the upload of a
+ * Large circuits: two keep the chip busy when witnesses are resident in HBM, a third and fourth hide the upload of a
  * host witness (a proof cannot start before its witness has arrived).  Small circuits (below ~2^19) are
- * bound by the serial latency of their ~80 small kernels, not by throughput: there more proofs in flight
- * is what fills the GPU (2^16: 2.4 ms per proof with three in flight).  zk_prove_collect blocks until the OLDEST submitted proof is complete
+ * bound by the serial latency of their ~60 small kernels, not by throughput: there more proofs in flight
+ * (on the prover's four lanes of streams) and batched submissions are what fills the GPU.  zk_prove_collect blocks until the OLDEST submitted proof is complete
  * and writes it.  d_wtns must stay valid (and unmodified) until its proof has been collected;
  * r32/s32 are copied at submit (NULL = random, drawn at collect).  On a sharded prover the pair is
  * zk_prove_dev_submit (r32/s32 ignored) + zk_prove_msm_collect, which hands back this shard's
