@@ -2,18 +2,20 @@
 // ParallelMultiexp behind Curve::multiMulByScalar (call sites src/groth16.cpp:173,183,190,197,204).
 //
 // MI355X design (ffiasm keeps nThreads x 2^c per-thread bucket arrays; that makes no sense here):
-//   1. k_msm_digits       : signed c-bit digits of every scalar, window-major 16-bit codes
-//   2. k_msm_count_lds    : per-(window, slice) histograms entirely in LDS; k_scan_* : exclusive scan
-//   3. k_msm_scatter_lds  : counting sort of (point index | sign) into bucket order, LDS-ranked
-//      (1-3 run ONCE per scalar vector: the witness sort is shared by MSM A, B1, B2, C,
+//   1. k_msm_digits       : signed c-bit digits of every scalar, window-major 32-bit codes (bit 31 = sign, low bits =
+//      bucket key; with window-precomputed tables every window shares ONE bucket set, and a batch of B scalar vectors
+//      — several small proofs in one set of launches — gets one set per vector)
+//   2. k_bin_count / k_bin_scatter : partition the codes by their high key bits into <= 256 bins (LDS-staged);
+//      k_bin_count_lds / k_bin_scatter_lds : counting sort of every bin with its histogram in LDS; k_scan_* between
+//      (1-2 run ONCE per scalar vector: the witness sort is shared by MSM A, B1, B2, C,
 //       which the reference recomputes four times, src/groth16.cpp:183-204)
-//   4. k_msm_accum_l1/_ln : load-balanced segmented accumulation — every lane mixed-adds a
-//      fixed-size chunk of the bucket-sorted list into XYZZ accumulators in VGPRs (next point
-//      prefetched); runs cut by chunk edges are merged by recursively shrinking levels
-//   5. k_msm_reduce_chunks / k_msm_reduce_final : sum_k (k+1)*B_k per window via chunked
-//      running sums + an LDS tree
-//   6. host: Horner over the W window sums (host_tail.cpp) — 256 serial doublings are
-//      30x faster on one CPU core than on one GPU lane.
+//   3. k_msm_accum_l1 / _l1_g2s : load-balanced segmented accumulation — every lane mixed-adds an equal share of
+//      the bucket-sorted list into XYZZ accumulators in VGPRs (next point prefetched; G2 split across lane pairs);
+//      k_msm_accum_pair / _wave : runs cut by chunk edges are merged by wave-parallel segmented scans, level by level
+//   4. bucket reduction sum_k (k+1)*B_k per bucket set: k_msm_reduce_chunks / _tree (chunked running sums + LDS tree)
+//      for large sets, k_msm_reduce_bits_block / _top (one binary tree of bit sums, c-1 additions deep) for small ones
+//   5. host (host_tail.cpp): the serial rest — Horner over the windows (plain tables) or over the c bit sums, and the
+//      final assembly: serial doublings are 30x faster on one CPU core than on one GPU lane.
 // Signed digits halve the bucket count; scalars are reduced mod r first so any 256-bit
 // input is accepted like the reference's raw-byte interface.
 #include <stdlib.h>
