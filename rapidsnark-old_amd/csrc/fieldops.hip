@@ -49,9 +49,14 @@ void launch_fq_mul_vec(Fq *out, const Fq *a, const Fq *b, uint64_t n, hipStream_
 // CSR built once at create time needs neither locks nor atomics.  The zkey stores
 // value*2^512; create rescales it to value*2^522 so that one 2^-261 Montgomery product with
 // the standard-form witness gives w*value in this library's 2^261 form (field29.hpp).
-__global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n) {
+// blockIdx.y = vector of a batched submission: its witness at wtns + y * wtns_stride, its a|b|c at + y * abc_stride
+__global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, uint64_t abc_stride, uint64_t wtns_stride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    a += (uint64_t)blockIdx.y * abc_stride;
+    b += (uint64_t)blockIdx.y * abc_stride;
+    c += (uint64_t)blockIdx.y * abc_stride;
+    wtns += (uint64_t)blockIdx.y * wtns_stride;
     Fr29 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; m++) {
@@ -75,8 +80,8 @@ __global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev cs
     store_el(c + i, Fr29::store(Fr29::mul(acc[0], acc[1])));
 }
 
-void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_spmv_abc, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, csr, wtns, n);
+void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s, uint32_t vectors, uint64_t abc_stride, uint64_t wtns_stride) {
+    hipLaunchKernelGGL(k_spmv_abc, dim3((n + 255) / 256, vectors ? vectors : 1), dim3(256), 0, s, a, b, c, csr, wtns, n, abc_stride, wtns_stride);
     ZK_LAUNCH_OK("spmv_abc");
 }
 

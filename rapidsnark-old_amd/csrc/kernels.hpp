@@ -19,7 +19,8 @@ struct CsrDev {
     const uint32_t *col;      // nnz: signal index s
     const Fr *val;            // nnz: coefficient (value*R^2 as stored in the zkey)
 };
-void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s);
+void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s, uint32_t vectors = 1, uint64_t abc_stride = 0,
+                     uint64_t wtns_stride = 0);     // vectors > 1: a batched submission, vector v at + v * stride
 // Row-sorted CSR from the zkey's coefficient records (section 4 after its u32 count: 44-byte packed
 // {u32 matrix, u32 row, u32 signal, 32-byte value}, src/groth16.hpp:27-35), built on the device.
 // rowptr: 2n + 1 words + msm_scan_extra_words(2n) of scan scratch; cursor: 2n words of scratch;
@@ -81,7 +82,7 @@ void launch_fr_scale_by_table(Fr *data, uint64_t stride_elems, uint32_t batch, c
 void launch_fr_scale_const(Fr *data, const Fr *k, uint64_t n, hipStream_t s);
 void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s);
 // h[i] = fromMontgomery(a[i]*b[i] - c[i])  (src/groth16.cpp:158-163)
-void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s);
+void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s, uint32_t vectors = 1, uint64_t abc_stride = 0);
 
 // ---------------------------------------------------------------- msm.hip
 struct MsmPlan {

@@ -398,17 +398,22 @@ void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s) {
 }
 
 // h[i] = fromMontgomery(a[i]*b[i] - c[i])  (src/groth16.cpp:158-163): standard-form MSM scalars
-__global__ __launch_bounds__(256) void k_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n) {
+// blockIdx.y = vector of a batched submission (a|b|c at + y * abc_stride, h at + y * n)
+__global__ __launch_bounds__(256) void k_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, uint64_t abc_stride) {
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
+    a += (uint64_t)blockIdx.y * abc_stride;
+    b += (uint64_t)blockIdx.y * abc_stride;
+    c += (uint64_t)blockIdx.y * abc_stride;
+    h += (uint64_t)blockIdx.y * n;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
         Fr29 t = Fr29::sub(Fr29::mul(Fr29::load(load_el(a + i)), Fr29::load(load_el(b + i))), Fr29::load(load_el(c + i)));
         store_el(h + i, Fr29::store(Fr29::from_mont(t)));
     }
 }
-void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s) {
+void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s, uint32_t vectors, uint64_t abc_stride) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_abc_to_h, dim3((uint32_t)g), dim3(256), 0, s, h, a, b, c, n);
+    hipLaunchKernelGGL(k_abc_to_h, dim3((uint32_t)g, vectors ? vectors : 1), dim3(256), 0, s, h, a, b, c, n, abc_stride);
     ZK_LAUNCH_OK("abc_to_h");
 }
 

@@ -873,8 +873,8 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     const uint64_t nl = p->nloc;
     Fr *abc = c.abc;
     CsrDev csr{p->csr_rowptr.p, p->csr_col.p, p->csr_val.p};
-    for (uint32_t v = 0; v < q.count; v++)         // (a batch: vector v's a|b|c behind vector v-1's; unused vectors are skipped)
-        launch_spmv_abc(abc + 3 * nl * v, abc + 3 * nl * v + nl, abc + 3 * nl * v + 2 * nl, csr, d_wtns + (uint64_t)p->nVars * v, (uint32_t)nl, s);
+    // (a batch: vector v's a|b|c behind vector v-1's; unused vectors are skipped)
+    launch_spmv_abc(abc, abc + nl, abc + 2 * nl, csr, d_wtns, (uint32_t)nl, s, q.count, 3 * nl, p->nVars);
     c.mark(1);
     if (p->part && !p->have_peers && p->pk_use) launch_chunk_pack(p->pk_use, abc, 3, p->logn, p->log_shards, s);   // -> all_to_all #1
     p->phase_open = si;
@@ -937,8 +937,7 @@ void phase_back(zk_prover *p) {
     Fr *abc = c.abc;
     if (p->part && !p->have_peers) launch_chunk_unpack(abc, p->pk_use, 3, p->logn, p->log_shards, s);
     // 5: h = fromMontgomery(a.b - c)  (src/groth16.cpp:157-163)
-    for (uint32_t v = 0; v < q.count; v++)
-        launch_abc_to_h(c.h + nl * v, abc + 3 * nl * v, abc + 3 * nl * v + nl, abc + 3 * nl * v + 2 * nl, nl, s);
+    launch_abc_to_h(c.h, abc, abc + nl, abc + 2 * nl, nl, s, q.count, 3 * nl);
     if (q.count < p->batch) HIP_TRY(hipMemsetAsync(c.h + nl * q.count, 0, (size_t)(p->batch - q.count) * nl * sizeof(Fr), s));    // h of an unused vector: no digits
     c.mark(2);
     c.sort_h->run(c.h + (p->part ? 0 : p->sh.lo), s);
