@@ -601,14 +601,19 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
         XYZZ<FR> acc = XYZZ<FR>::inf();
         Affine<F> nextP;                 // raw words: the next point is in flight while this one is added
         bool nextNeg = false, nextSkip = false;
-        auto fetch = [&](uint32_t pos) {
-            uint32_t ent = entries[pos];
-            uint32_t idx = ent & 0x7fffffffu;
+        // two loads deep: the ENTRY of position e+2 is in flight while the POINT of e+1 is, so the address of a point
+        // load never waits for its entry (a wave's three resident siblings run in phase with it — same work, same
+        // start — and do not cover that wait)
+        uint32_t entNext = entries[lo];
+        auto fetch = [&](uint32_t pos) {          // point of position pos (its entry is in entNext), entry of pos + 1
+            const uint32_t ent = entNext;
+            const uint32_t idx = ent & 0x7fffffffu;
             nextNeg = (ent >> 31) != 0;
             nextSkip = idx < idx_min;
             const Affine<F> *src = points + (nextSkip ? 0 : (idx - idx_sub) & batch.gather_mask);
             nextP.x = load_el(&src->x);
             nextP.y = load_el(&src->y);
+            if (pos + 1 < hi) entNext = entries[pos + 1];
         };
         uint32_t e = lo;
         fetch(e);
@@ -683,14 +688,16 @@ __global__ __launch_bounds__(256) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *
         XYZZ<Fq2s> acc = XYZZ<Fq2s>::inf();
         Fq nextX, nextY;                 // raw words of this lane's component of the next point
         bool nextNeg = false, nextSkip = false;
+        uint32_t entNext = entries[lo];               // two loads deep, as in the G1 kernel
         auto fetch = [&](uint32_t pos) {
-            uint32_t ent = entries[pos];
-            uint32_t idx = ent & 0x7fffffffu;
+            const uint32_t ent = entNext;
+            const uint32_t idx = ent & 0x7fffffffu;
             nextNeg = (ent >> 31) != 0;
             nextSkip = idx < idx_min;
             const Fq *src = reinterpret_cast<const Fq *>(points + (nextSkip ? 0 : idx - idx_sub)) + comp;
             nextX = load_el(src);
             nextY = load_el(src + 2);
+            if (pos + 1 < hi) entNext = entries[pos + 1];
         };
         uint32_t e = lo;
         fetch(e);
