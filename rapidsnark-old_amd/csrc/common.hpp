@@ -4,8 +4,21 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <stdlib.h>
 
 namespace zk {
+
+// Measurement probes (chunk sizes, gather confinement, workgroup rounds ...) exist only in a build made with
+// -DZK_PROBES (make probes -> libzkhip_probes.so, loaded through ZKHIP_LIB for same-box A/Bs).  The shipped
+// library reads the variables INTEGRATION.md section 5 lists and nothing else: probe_env() is a constant there.
+static inline const char *probe_env(const char *name) {
+#ifdef ZK_PROBES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // thread-local message behind zk_last_error()
 void set_error(const std::string &msg);

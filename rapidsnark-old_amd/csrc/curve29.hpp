@@ -25,8 +25,9 @@ ZK_HD void madd(XYZZ<Fq29> &acc, const Affine<Fq29> &p) {
         acc = XYZZ<F>{p.x, F::carry(p.y), F::one(), F::one()};   // p.y may be a lazily negated value
         return;
     }
-    F U2 = F::mul(p.x, acc.zz);
-    F S2 = F::mul(p.y, acc.zzz);
+    // products in PAIRS of independent chains (field29.hpp run2): (U2, S2), (PP, R2), (PPP, Q), (Y3, ZZ3); ZZZ3 is alone
+    F U2, S2;
+    F::mul2(U2, p.x, acc.zz, S2, p.y, acc.zzz);
     F P = F::sub_nc(U2, acc.x);
     F R = F::sub_nc(S2, acc.y);
     if (P.is_zero()) {
@@ -34,16 +35,17 @@ ZK_HD void madd(XYZZ<Fq29> &acc, const Affine<Fq29> &p) {
         else acc = XYZZ<F>::inf();
         return;
     }
-    F PP = F::sqr(P);
-    F PPP = F::mul(P, PP);
-    F Q = F::mul(acc.x, PP);
-    F R2 = F::sqr(R);
+    F PP, R2;
+    F::sqr2(PP, P, R2, R);
+    F PPP, Q;
+    F::mul2(PPP, P, PP, Q, acc.x, PP);
     F X3;
 #pragma unroll
     for (int i = 0; i < 9; i++) X3.l[i] = R2.l[i] - PPP.l[i] - (Q.l[i] << 1);
     X3 = F::carry(X3);
-    F Y3 = F::mul_add2(R, F::sub_nc(Q, X3), F::neg_lazy(acc.y), PPP);
-    acc.zz = F::mul(acc.zz, PP);
+    const F D = F::sub_nc(Q, X3), NY = F::neg_lazy(acc.y);
+    F Y3;
+    F::run2(Y3, typename F::JMulAdd2{R, D, NY, PPP}, acc.zz, typename F::JMul{acc.zz, PP});      // zz' in place: column k writes limb k-9, reads limbs >= k-8
     acc.zzz = F::mul(acc.zzz, PPP);
     acc.x = X3;
     acc.y = Y3;
@@ -166,13 +168,33 @@ struct Fq2s {
         return Fq2s{Fq29::mul_add2(x.a0, y.v, x.a1s, other(y.v))};
     }
     // re = (a0 + a1)(a0 - a1), im = 2 a0 a1 = (a0 + a0) * a1:  u = a0 + partner, w = own - (even ? a1 : 0)
-    static __device__ __forceinline__ Fq2s sqr(const Fq2s &x) {
+    static __device__ __forceinline__ void sqr_operands(Fq29 &u, Fq29 &w, const Fq2s &x) {
         const Fq29 a0 = from_even(x.v), xo = other(x.v);
         const int keep = odd() ? 0 : -1;
         Fq29 t;
 #pragma unroll
         for (int i = 0; i < 9; i++) t.l[i] = xo.l[i] & keep;
-        return Fq2s{Fq29::mul(Fq29::add_nc(a0, xo), Fq29::sub(x.v, t))};
+        u = Fq29::add_nc(a0, xo);
+        w = Fq29::sub(x.v, t);
+    }
+    static __device__ __forceinline__ Fq2s sqr(const Fq2s &x) {
+        Fq29 u, w;
+        sqr_operands(u, w, x);
+        return Fq2s{Fq29::mul(u, w)};
+    }
+    // pairs of independent products: the two chains interleaved (field29.hpp run2)
+    static __device__ __forceinline__ void mul2(Fq2s &r0, const Pre &x0, const Fq2s &y0, Fq2s &r1, const Pre &x1, const Fq2s &y1) {
+        const Fq29 yo0 = other(y0.v), yo1 = other(y1.v);
+        Fq29::run2(r0.v, Fq29::JMulAdd2{x0.a0, y0.v, x0.a1s, yo0}, r1.v, Fq29::JMulAdd2{x1.a0, y1.v, x1.a1s, yo1});
+    }
+    static __device__ __forceinline__ void mul2(Fq2s &r0, const Fq2s &x0, const Fq2s &y0, Fq2s &r1, const Fq2s &x1, const Fq2s &y1) {
+        mul2(r0, prepare(x0), y0, r1, prepare(x1), y1);
+    }
+    static __device__ __forceinline__ void sqr2(Fq2s &r0, const Fq2s &x0, Fq2s &r1, const Fq2s &x1) {
+        Fq29 u0, w0, u1, w1;
+        sqr_operands(u0, w0, x0);
+        sqr_operands(u1, w1, x1);
+        Fq29::mul2(r0.v, u0, w0, r1.v, u1, w1);
     }
 };
 
@@ -185,8 +207,9 @@ __device__ __forceinline__ void madd(XYZZ<Fq2s> &acc, const Affine<Fq2s> &p) {
         acc = XYZZ<F>{p.x, F{B::carry(p.y.v)}, F::one(), F::one()};
         return;
     }
-    F U2 = F::mul(p.x, acc.zz);
-    F S2 = F::mul(p.y, acc.zzz);
+    // every product has an independent sibling: (U2, S2), (PP, R2), (PPP, Q), (zz', T1), (zzz', T2)
+    F U2, S2;
+    F::mul2(U2, p.x, acc.zz, S2, p.y, acc.zzz);
     F P{B::sub_nc(U2.v, acc.x.v)};
     F R{B::sub_nc(S2.v, acc.y.v)};
     if (P.is_zero()) {
@@ -194,20 +217,19 @@ __device__ __forceinline__ void madd(XYZZ<Fq2s> &acc, const Affine<Fq2s> &p) {
         else acc = XYZZ<F>::inf();
         return;
     }
-    F PP = F::sqr(P);
+    F PP, R2;
+    F::sqr2(PP, P, R2, R);
     const F::Pre pp = F::prepare(PP);             // PP and PPP enter three and two products: exchanged once each
-    acc.zz = F::mul(pp, acc.zz);
-    F Q = F::mul(pp, acc.x);
-    F PPP = F::mul(pp, P);
+    F PPP, Q;
+    F::mul2(PPP, pp, P, Q, pp, acc.x);
     const F::Pre ppp = F::prepare(PPP);
-    acc.zzz = F::mul(ppp, acc.zzz);
-    F T2 = F::mul(ppp, acc.y);
-    F R2 = F::sqr(R);
 #pragma unroll
     for (int i = 0; i < 9; i++) acc.x.v.l[i] = R2.v.l[i] - PPP.v.l[i] - (Q.v.l[i] << 1);
     acc.x.v = B::carry(acc.x.v);                  // X3
-    F D{B::sub_nc(Q.v, acc.x.v)};
-    F T1 = F::mul(R, D);
+    const F D{B::sub_nc(Q.v, acc.x.v)};
+    F T1, T2;
+    F::mul2(acc.zz, pp, acc.zz, T1, F::prepare(R), D);
+    F::mul2(acc.zzz, ppp, acc.zzz, T2, ppp, acc.y);
     acc.y = F{B::sub(T1.v, T2.v)};                // carried: keeps the next S2 - y tight
 }
 #endif

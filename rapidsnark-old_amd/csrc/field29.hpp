@@ -39,6 +39,55 @@ struct Fr29Params {
     static constexpr int32_t K_OUT[9] = {268435451, 78749922, 406014571, 418196286, 342025071, 297253948, 482187706, 406012155, 920183};   // 2^256 mod r
 };
 
+// ---- The multiply-accumulate of the column chains: three builds of the same arithmetic.
+// Left as C (acc += (int64_t)a * b) hipcc (i) splits every column into independent chains and merges them with a
+// 64-bit add per column (17 extra 4-cycle instructions per product) and (ii) — whenever known-bits analysis proves one
+// factor non-negative (a limb just masked out of a word) — rewrites sext x sext as sext x zext, which no longer matches
+// v_mad_i64_i32 and is expanded into v_mad_u64_u32 plus a correction MAD for the sign word (seen: 386 extra MADs per G1
+// addition after an unrelated change to the loop around it; the empty-asm barriers in from_words / out_limb hide the sign).
+//   default        : PAIRS of independent products (run2) as blocks of inline-asm MADs with the two chains alternating
+//                    (mad_blocks.inc; hipcc puts an s_nop behind every asm statement whose result a later asm reads, so
+//                    the unit is a block, not a MAD); lone products (run1) as C column sums
+//   ZK_STMT_MAD    : one asm statement per MAD everywhere (measured slower: profiles/r03a_mul_rate.txt)
+//   ZK_COMPILER_MAD: C column sums everywhere
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_COMPILER_MAD)
+#if defined(ZK_STMT_MAD)
+#define ZK_ASM_MAD 1
+#else
+#define ZK_BLOCK_MAD 1
+#endif
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_STMT_MAD)
+#define ZK_SIGN_BARRIER(x) asm("" : "+v"(x))
+#else
+#define ZK_SIGN_BARRIER(x) ((void)0)
+#endif
+#if defined(ZK_ASM_MAD)
+__device__ __forceinline__ int64_t zk_mad(int64_t acc, int32_t a, int32_t b) {
+    uint64_t cy;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
+    return acc;
+}
+__device__ __forceinline__ int64_t zk_mad0(int32_t a, int32_t b) {        // first term of a chain: addend = inline constant 0
+    int64_t acc;
+    uint64_t cy;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(cy) : "v"(a), "v"(b));
+    return acc;
+}
+__device__ __forceinline__ int64_t zk_mad_s(int64_t acc, int32_t a, int32_t s) {      // s: wave-uniform (modulus limb) in an SGPR
+    uint64_t cy;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "s"(s));
+    return acc;
+}
+#else
+ZK_HD int64_t zk_mad(int64_t acc, int32_t a, int32_t b) { return acc + (int64_t)a * b; }
+ZK_HD int64_t zk_mad0(int32_t a, int32_t b) { return (int64_t)a * b; }
+ZK_HD int64_t zk_mad_s(int64_t acc, int32_t a, int32_t s) { return acc + (int64_t)a * s; }
+#endif
+#if defined(ZK_BLOCK_MAD)
+#include "mad_blocks.inc"
+#endif
+
 template <class PR>
 struct Fp29 {
     int32_t l[9];
@@ -52,16 +101,26 @@ struct Fp29 {
     static constexpr const int32_t (&K_IN)[9] = PR::K_IN;
     static constexpr const int32_t (&K_OUT)[9] = PR::K_OUT;
 
-    // Modulus limb for the reduction MADs.  On the device the value is pinned in an SGPR through an (empty,
-    // CSE-able) asm: left to itself the compiler parks p[1..8] in 8 VGPRs that it re-loads from a constant
-    // table inside every loop iteration of the bucket kernels (two global_load_dwordx4 + a wait per point).
+    // Modulus limb k as a LITERAL.  P[k] read through the constexpr table is a load on the device (hipcc emits
+    // constexpr class statics as externally initialised constant memory and does not fold reads of them): the
+    // bucket kernels then re-load the nine limbs with three vector loads inside every loop iteration, and the
+    // in-order vmcnt wait for them also waits for the prefetch of the next point issued just before.  The
+    // local constexpr copies below are folded by the front end.
+    template <const int32_t (&A)[9]>
+    ZK_HD static constexpr int32_t LIT(int k) {
+        constexpr int32_t c0 = A[0], c1 = A[1], c2 = A[2], c3 = A[3], c4 = A[4], c5 = A[5], c6 = A[6], c7 = A[7], c8 = A[8];
+        return k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : k == 3 ? c3 : k == 4 ? c4 : k == 5 ? c5 : k == 6 ? c6 : k == 7 ? c7 : c8;
+    }
+    ZK_HD static constexpr int32_t PL(int k) { return LIT<PR::P>(k); }
+    // Modulus limb for the reduction MADs, pinned in an SGPR on the device through an (empty, CSE-able) asm:
+    // left to itself the compiler parks p[1..8] in 8 VGPRs.
     ZK_HD static int32_t PS(int k) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_SGPR_MODULUS)
         int32_t r;
-        asm("" : "=s"(r) : "0"(__builtin_amdgcn_readfirstlane(P[k])));
+        asm("" : "=s"(r) : "0"(PL(k)));
         return r;
 #else
-        return P[k];
+        return PL(k);
 #endif
     }
     ZK_HD static Fq29 zero() {
@@ -73,19 +132,19 @@ struct Fp29 {
     ZK_HD static Fq29 one() {
         Fq29 r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = ONE[i];
+        for (int i = 0; i < 9; i++) r.l[i] = LIT<PR::ONE>(i);
         return r;
     }
     ZK_HD static Fq29 k_in() {
         Fq29 r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = K_IN[i];
+        for (int i = 0; i < 9; i++) r.l[i] = LIT<PR::K_IN>(i);
         return r;
     }
     ZK_HD static Fq29 k_out() {
         Fq29 r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = K_OUT[i];
+        for (int i = 0; i < 9; i++) r.l[i] = LIT<PR::K_OUT>(i);
         return r;
     }
     ZK_HD bool is_zero_raw() const {
@@ -139,102 +198,209 @@ struct Fp29 {
         return carry(t);
     }
 
-    // Montgomery product a*b*2^-261 (mod p), product-scanning: every column is a chain of
-    // v_mad_i64_i32 into one 64-bit accumulator; |column| < 18 * 2^58.1 < 2^63.
-    ZK_HD static Fq29 mul(const Fq29 &a, const Fq29 &b) {
-        int64_t acc = 0;
-        int32_t m[9];
-        Fq29 r;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-#pragma unroll
-            for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * PS(k - i);
-            m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
-            acc += (int64_t)m[k] * PS(0);
-            acc >>= 29;          // exact: the low 29 bits are zero now
-        }
-#pragma unroll
-        for (int k = 9; k < 17; k++) {
-#pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * PS(k - i);
-            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
-            acc >>= 29;
-        }
-        r.l[8] = (int32_t)acc;
-        return r;
+    // ---- Montgomery products a*b*2^-261 (mod p), product-scanning over 17 columns of v_mad_i64_i32.
+    // A column is a CHAIN of MADs into one 64-bit accumulator (|column| < 27 * 2^58 < 2^63 even for the fused
+    // double product); the carry of column k (acc >> 29) is the addend of column k+1's first MAD, so there is no
+    // 64-bit add per column.  A "job" lists the operand products of a column; the engine below runs
+    //   run2: TWO independent jobs with their chains interleaved MAD by MAD — the dependent-issue latency of one
+    //         chain is covered by the other (what hipcc's split-and-merge bought, without its 17 merge adds), and no
+    //         result is consumed by the very next instruction (hipcc puts an s_nop behind an inline asm whose
+    //         result the next instruction reads);
+    //   run1: one job, its operand products and its reduction products as two interleaved chains merged by one
+    //         64-bit add per column (a product that has no independent sibling).
+    // Per product: 162 MADs + 17 shifts + 9 v_mul_lo + 17 masks (+ 17 adds in run1).
+    // masked limb of a result.  C column sums only: the mask tells the optimiser the limb is non-negative (see from_words)
+    ZK_HD static int32_t out_limb(int64_t acc) {
+        int32_t v = (int32_t)((uint32_t)acc & (uint32_t)MASK);
+        ZK_SIGN_BARRIER(v);
+        return v;
     }
-    // a^2 * 2^-261: symmetric terms once with a doubled operand — 45 product MADs instead of 81
-    ZK_HD static Fq29 sqr(const Fq29 &a) {
+    ZK_HD static int32_t mont_m(int64_t acc) { return (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK); }
+    ZK_HD static constexpr int col_lo(int k) { return k < 9 ? 0 : k - 8; }
+    ZK_HD static constexpr int col_n(int k) { return k < 9 ? k + 1 : 17 - k; }          // a_i * b_(k-i) terms of column k
+    struct JMul {                       // a * b
+        const Fp29 &a, &b;
+        ZK_HD static constexpr int n(int k) { return col_n(k); }
+        ZK_HD void term(int64_t &acc, int k, int t, bool first) const {
+            const int i = col_lo(k) + t;
+            acc = first ? zk_mad0(a.l[i], b.l[k - i]) : zk_mad(acc, a.l[i], b.l[k - i]);
+        }
+        ZK_HD void ops(int k, int t, int32_t &x, int32_t &y) const {
+            const int i = col_lo(k) + t;
+            x = a.l[i];
+            y = b.l[k - i];
+        }
+    };
+    struct JSqr {                       // a * a: symmetric terms once with a doubled operand — 45 product MADs instead of 81
+        const Fp29 &a;
         int32_t a2[9];
+        ZK_HD explicit JSqr(const Fp29 &x) : a(x) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+            for (int i = 0; i < 9; i++) a2[i] = x.l[i] << 1;
+        }
+        ZK_HD static constexpr int nsym(int k) { return (k + 1) / 2 - col_lo(k); }       // i in [lo, k/2)
+        ZK_HD static constexpr int n(int k) { return nsym(k) + ((k & 1) == 0 ? 1 : 0); }
+        ZK_HD void term(int64_t &acc, int k, int t, bool first) const {
+            if (t < nsym(k)) {
+                const int i = col_lo(k) + t;
+                acc = first ? zk_mad0(a2[i], a.l[k - i]) : zk_mad(acc, a2[i], a.l[k - i]);
+            } else {
+                acc = first ? zk_mad0(a.l[k >> 1], a.l[k >> 1]) : zk_mad(acc, a.l[k >> 1], a.l[k >> 1]);
+            }
+        }
+        ZK_HD void ops(int k, int t, int32_t &x, int32_t &y) const {
+            if (t < nsym(k)) {
+                const int i = col_lo(k) + t;
+                x = a2[i];
+                y = a.l[k - i];
+            } else {
+                x = y = a.l[k >> 1];
+            }
+        }
+    };
+    struct JMulAdd2 {                   // a * b + c * d with ONE reduction
+        const Fp29 &a, &b, &c, &d;
+        ZK_HD static constexpr int n(int k) { return 2 * col_n(k); }
+        ZK_HD void term(int64_t &acc, int k, int t, bool first) const {
+            const int i = col_lo(k) + (t >> 1);
+            if (t & 1) acc = zk_mad(acc, c.l[i], d.l[k - i]);
+            else acc = first ? zk_mad0(a.l[i], b.l[k - i]) : zk_mad(acc, a.l[i], b.l[k - i]);
+        }
+        ZK_HD void ops(int k, int t, int32_t &x, int32_t &y) const {
+            const int i = col_lo(k) + (t >> 1);
+            x = (t & 1) ? c.l[i] : a.l[i];
+            y = (t & 1) ? d.l[k - i] : b.l[k - i];
+        }
+    };
+#if defined(ZK_BLOCK_MAD)
+    // Block form: the MADs of a column go out as a few multi-instruction asm statements (mad_blocks.inc) in which the
+    // two chains alternate — one s_nop per block instead of one per MAD.  Columns are template instances (block sizes
+    // must be constants where the statement is chosen).
+    template <int K, class J0, class J1>
+    __device__ __forceinline__ static void col2(int64_t &acc0, int64_t &acc1, int32_t (&m0)[9], int32_t (&m1)[9], Fp29 &r0, const J0 &j0, Fp29 &r1,
+                                                const J1 &j1) {
+        constexpr int n0 = J0::n(K), n1 = J1::n(K), nmin = n0 < n1 ? n0 : n1;
+        int32_t x0[18], y0[18], x1[18], y1[18];
+#pragma unroll
+        for (int t = 0; t < 18; t++) {
+            if (t < n0) j0.ops(K, t, x0[t], y0[t]);
+            if (t < n1) j1.ops(K, t, x1[t], y1[t]);
+        }
+        if constexpr (nmin > 0) zk_blk_dvv(nmin < 6 ? nmin : 6, acc0, acc1, x0, y0, x1, y1);
+        if constexpr (nmin > 6) zk_blk_dvv(nmin - 6 < 6 ? nmin - 6 : 6, acc0, acc1, x0 + 6, y0 + 6, x1 + 6, y1 + 6);
+        if constexpr (nmin > 12) zk_blk_dvv(nmin - 12, acc0, acc1, x0 + 12, y0 + 12, x1 + 12, y1 + 12);
+        if constexpr (n0 > nmin) zk_blk_svv(n0 - nmin < 9 ? n0 - nmin : 9, acc0, x0 + nmin, y0 + nmin);
+        if constexpr (n0 > nmin + 9) zk_blk_svv(n0 - nmin - 9, acc0, x0 + nmin + 9, y0 + nmin + 9);
+        if constexpr (n1 > nmin) zk_blk_svv(n1 - nmin < 9 ? n1 - nmin : 9, acc1, x1 + nmin, y1 + nmin);
+        if constexpr (n1 > nmin + 9) zk_blk_svv(n1 - nmin - 9, acc1, x1 + nmin + 9, y1 + nmin + 9);
+        constexpr int rlo = K < 9 ? 0 : K - 8, rhi = K < 9 ? K : 9, nr = rhi - rlo;
+        int32_t pr[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (i < nr) pr[i] = PS(K - (rlo + i));
+        if constexpr (nr > 0) zk_blk_dmp(nr < 8 ? nr : 8, acc0, acc1, m0 + rlo, m1 + rlo, pr);
+        if constexpr (nr > 8) zk_blk_dmp(nr - 8, acc0, acc1, m0 + rlo + 8, m1 + rlo + 8, pr + 8);
+        if constexpr (K < 9) {
+            m0[K] = mont_m(acc0);
+            m1[K] = mont_m(acc1);
+            zk_blk_dmp1(acc0, acc1, m0[K], m1[K], PS(0));
+        } else {
+            r0.l[K - 9] = out_limb(acc0);
+            r1.l[K - 9] = out_limb(acc1);
+        }
+        acc0 >>= 29;
+        acc1 >>= 29;
+        if constexpr (K < 16) col2<K + 1>(acc0, acc1, m0, m1, r0, j0, r1, j1);
+    }
+    template <class J0, class J1>
+    __device__ __forceinline__ static void run2(Fp29 &r0, const J0 &j0, Fp29 &r1, const J1 &j1) {
+        int64_t acc0 = 0, acc1 = 0;
+        int32_t m0[9], m1[9];
+        col2<0>(acc0, acc1, m0, m1, r0, j0, r1, j1);
+        r0.l[8] = (int32_t)acc0;
+        r1.l[8] = (int32_t)acc1;
+    }
+#else
+    template <class J0, class J1>
+    ZK_HD static void run2(Fp29 &r0, const J0 &j0, Fp29 &r1, const J1 &j1) {
+        int64_t acc0 = 0, acc1 = 0;
+        int32_t m0[9], m1[9];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            const int n0 = J0::n(k), n1 = J1::n(k), nmax = n0 > n1 ? n0 : n1;
+#pragma unroll
+            for (int t = 0; t < nmax; t++) {
+                if (t < n0) j0.term(acc0, k, t, k == 0 && t == 0);
+                if (t < n1) j1.term(acc1, k, t, k == 0 && t == 0);
+            }
+#pragma unroll
+            for (int i = (k < 9 ? 0 : k - 8); i < (k < 9 ? k : 9); i++) {
+                acc0 = zk_mad_s(acc0, m0[i], PS(k - i));
+                acc1 = zk_mad_s(acc1, m1[i], PS(k - i));
+            }
+            if (k < 9) {
+                m0[k] = mont_m(acc0);
+                m1[k] = mont_m(acc1);
+                acc0 = zk_mad_s(acc0, m0[k], PS(0));
+                acc1 = zk_mad_s(acc1, m1[k], PS(0));
+            } else {
+                r0.l[k - 9] = out_limb(acc0);
+                r1.l[k - 9] = out_limb(acc1);
+            }
+            acc0 >>= 29;         // k < 9: exact, the low 29 bits are zero now
+            acc1 >>= 29;
+        }
+        r0.l[8] = (int32_t)acc0;
+        r1.l[8] = (int32_t)acc1;
+    }
+#endif
+    template <class J>
+    ZK_HD static Fp29 run1(const J &j) {
         int64_t acc = 0;
         int32_t m[9];
-        Fq29 r;
+        Fp29 r;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int k = 0; k < 17; k++) {
+#if defined(ZK_ASM_MAD) && !defined(ZK_SERIAL_CHAIN)
+            int64_t accp = 0;                              // operand products from zero; `acc` takes the reduction products
+            const int np = J::n(k), nr = (k < 9 ? k : 17 - k), nmax = np > nr ? np : nr;
 #pragma unroll
-            for (int i = 0; 2 * i < k; i++) acc += (int64_t)a2[i] * a.l[k - i];
-            if ((k & 1) == 0) acc += (int64_t)a.l[k >> 1] * a.l[k >> 1];
+            for (int t = 0; t < nmax; t++) {
+                if (t < np) j.term(accp, k, t, t == 0);
+                if (t < nr) {
+                    const int i = (k < 9 ? 0 : k - 8) + t;
+                    acc = zk_mad_s(acc, m[i], PS(k - i));
+                }
+            }
+            acc += accp;
+#else
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * PS(k - i);
-            m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
-            acc += (int64_t)m[k] * PS(0);
-            acc >>= 29;
-        }
+            for (int t = 0; t < J::n(k); t++) j.term(acc, k, t, k == 0 && t == 0);
 #pragma unroll
-        for (int k = 9; k < 17; k++) {
-#pragma unroll
-            for (int i = k - 8; 2 * i < k; i++) acc += (int64_t)a2[i] * a.l[k - i];
-            if ((k & 1) == 0) acc += (int64_t)a.l[k >> 1] * a.l[k >> 1];
-#pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * PS(k - i);
-            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
+            for (int i = (k < 9 ? 0 : k - 8); i < (k < 9 ? k : 9); i++) acc = zk_mad_s(acc, m[i], PS(k - i));
+#endif
+            if (k < 9) {
+                m[k] = mont_m(acc);
+                acc = zk_mad_s(acc, m[k], PS(0));
+            } else {
+                r.l[k - 9] = out_limb(acc);
+            }
             acc >>= 29;
         }
         r.l[8] = (int32_t)acc;
         return r;
     }
-    // (a*b + c*d) * 2^-261 with ONE reduction: both products share the column accumulators
-    // (|column| < 27 * 2^58 < 2^63).  The Fq2 product is two of these — same MAD count as
-    // Karatsuba but without its five add/sub + carry passes.
+    ZK_HD static Fq29 mul(const Fq29 &a, const Fq29 &b) { return run1(JMul{a, b}); }
+    ZK_HD static Fq29 sqr(const Fq29 &a) { return run1(JSqr(a)); }
+    // (a*b + c*d) * 2^-261 with ONE reduction: both products share the column accumulators.  The Fq2 product is two
+    // of these — same MAD count as Karatsuba but without its five add/sub + carry passes.
     static constexpr bool FUSED_MULADD = true;
-    ZK_HD static Fq29 mul_add2(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d) {
-        int64_t acc = 0;
-        int32_t m[9];
-        Fq29 r;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-#pragma unroll
-            for (int i = 0; i <= k; i++) {
-                acc += (int64_t)a.l[i] * b.l[k - i];
-                acc += (int64_t)c.l[i] * d.l[k - i];
-            }
-#pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * PS(k - i);
-            m[k] = (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK);
-            acc += (int64_t)m[k] * PS(0);
-            acc >>= 29;
-        }
-#pragma unroll
-        for (int k = 9; k < 17; k++) {
-#pragma unroll
-            for (int i = k - 8; i <= 8; i++) {
-                acc += (int64_t)a.l[i] * b.l[k - i];
-                acc += (int64_t)c.l[i] * d.l[k - i];
-            }
-#pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * PS(k - i);
-            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
-            acc >>= 29;
-        }
-        r.l[8] = (int32_t)acc;
-        return r;
+    ZK_HD static Fq29 mul_add2(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d) { return run1(JMulAdd2{a, b, c, d}); }
+    // pairs of independent products (the mixed additions of curve29.hpp are written in these)
+    ZK_HD static void mul2(Fq29 &r0, const Fq29 &a0, const Fq29 &b0, Fq29 &r1, const Fq29 &a1, const Fq29 &b1) {
+        run2(r0, JMul{a0, b0}, r1, JMul{a1, b1});
     }
+    ZK_HD static void sqr2(Fq29 &r0, const Fq29 &a0, Fq29 &r1, const Fq29 &a1) { run2(r0, JSqr(a0), r1, JSqr(a1)); }
     // limb-wise add / sub WITHOUT the carry pass.  Bound bookkeeping (see curve29.hpp): a product
     // tolerates |limb| <= 2^29+16 on both operands, or 2^30+32 on ONE of them; mul_add2 needs
     // <= 2^29+16 on all four.  The difference of two values with non-negative limbs (e.g. two
@@ -278,11 +444,11 @@ struct Fp29 {
         int64_t c = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            c += (int64_t)a.l[i] - (int64_t)k * P[i];
+            c += (int64_t)a.l[i] - (int64_t)k * PL(i);
             t.l[i] = (int32_t)((uint32_t)c & (uint32_t)MASK);
             c >>= 29;
         }
-        t.l[8] = (int32_t)(c + a.l[8] - (int64_t)k * P[8]);
+        t.l[8] = (int32_t)(c + a.l[8] - (int64_t)k * PL(8));
         return t;    // limbs 0..7 in [0, 2^29)
     }
     // exact: value == 0 (mod p).  After reduce_near_zero the value is in (-p, p): zero iff all limbs are.
@@ -294,7 +460,7 @@ struct Fp29 {
         if (t.l[8] < 0) {                          // negative: add p
             Fq29 u;
 #pragma unroll
-            for (int i = 0; i < 9; i++) u.l[i] = t.l[i] + P[i];
+            for (int i = 0; i < 9; i++) u.l[i] = t.l[i] + PL(i);
             t = carry_full(u);
         }
         return t;
@@ -312,6 +478,9 @@ struct Fp29 {
         r.l[6] = (int32_t)(((w[5] >> 14) | (w[6] << 18)) & (u32)MASK);
         r.l[7] = (int32_t)(((w[6] >> 11) | (w[7] << 21)) & (u32)MASK);
         r.l[8] = (int32_t)(w[7] >> 8);
+        // hide "this limb is non-negative" from the optimiser (see zk_mad above)
+#pragma unroll
+        for (int i = 0; i < 9; i++) ZK_SIGN_BARRIER(r.l[i]);
         return r;
     }
     ZK_HD static void to_words(u32 w[8], const Fq29 &c) {
@@ -346,7 +515,7 @@ struct Fp29 {
         for (int i = 0; i < 9 * 29; i++) {
             int32_t limb = 0;
 #pragma unroll
-            for (int k = 0; k < 9; k++) limb = (i / 29 == k) ? P[k] : limb;
+            for (int k = 0; k < 9; k++) limb = (i / 29 == k) ? PL(k) : limb;
             if (i < 29) limb -= 2;                      // p - 2 (P[0] >= 2)
             if ((limb >> (i % 29)) & 1) result = mul(result, base);
             base = sqr(base);

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include "kernels.hpp"
 #include "hipcheck.hpp"
+#include "common.hpp"
 #include "field29.hpp"
 #include "curve29.hpp"
 #include <string.h>
@@ -552,6 +553,11 @@ __device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes,
     const uint32_t c = (uint32_t)(((uint64_t)E + nlanes - 1) / nlanes);
     return c < chunk_min ? chunk_min : c;
 }
+#ifdef ZK_PROBES
+#define ZK_GATHER_ROW(i) ((i) & batch.gather_mask)
+#else
+#define ZK_GATHER_ROW(i) (i)
+#endif
 #define ACC_CHUNK_N 32u     // slots per unit at levels >= 2 used to SIZE the workspace (a G2 wave takes 32, a G1 wave 64)
 #define SLOT_EMPTY 0xffffffffu
 #define FLAG_STARTS 1u
@@ -596,6 +602,11 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
         }
         uint32_t b = bl;
         uint32_t bend = offsets[b + 1];
+        // The end of the bucket AFTER the current one, re-loaded at the top of every iteration (one cached dword next to
+        // the prefetch): a dependent load at the run's end — a run ends in ~46 % of a wave's iterations — cost a memory
+        // latency every time, and so does a load issued AT the run's end (the loop-top wait for the next entry is
+        // in-order: it would wait for that load too).
+        uint32_t bend2 = 0;
         bool started_before = offsets[b] < lo;
         typedef REGF FR;
         XYZZ<FR> acc = XYZZ<FR>::inf();
@@ -604,16 +615,20 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
         // two loads deep: the ENTRY of position e+2 is in flight while the POINT of e+1 is, so the address of a point
         // load never waits for its entry (a wave's three resident siblings run in phase with it — same work, same
         // start — and do not cover that wait)
+        // The loads are UNCONDITIONAL (positions past the chunk's end are clamped to its last entry and the result is
+        // never used): a load under `if (e < hi)` makes the compiler merge its result with the old value right behind
+        // the branch — an s_waitcnt vmcnt(0) straight after the issue, i.e. no prefetch at all.
         uint32_t entNext = entries[lo];
         auto fetch = [&](uint32_t pos) {          // point of position pos (its entry is in entNext), entry of pos + 1
             const uint32_t ent = entNext;
             const uint32_t idx = ent & 0x7fffffffu;
             nextNeg = (ent >> 31) != 0;
             nextSkip = idx < idx_min;
-            const Affine<F> *src = points + (nextSkip ? 0 : (idx - idx_sub) & batch.gather_mask);
+            bend2 = offsets[b + 2 < nbuckets_total ? b + 2 : nbuckets_total];
+            const Affine<F> *src = points + (nextSkip ? 0 : ZK_GATHER_ROW(idx - idx_sub));
             nextP.x = load_el(&src->x);
             nextP.y = load_el(&src->y);
-            if (pos + 1 < hi) entNext = entries[pos + 1];
+            entNext = entries[pos + 1 < hi ? pos + 1 : hi - 1];
         };
         uint32_t e = lo;
         fetch(e);
@@ -621,7 +636,7 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
             Affine<F> Pw = nextP;
             bool ng = nextNeg, skip = nextSkip;
             e++;
-            if (e < hi) fetch(e);
+            fetch(e < hi ? e : hi - 1);
             if (!skip) {
                 Affine<FR> P = to_reg_affine<F>(Pw);
                 if (ng) negate_y(P);
@@ -629,19 +644,21 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
             }
             if (e == bend || e == hi) {              // the run of bucket b ends here (or is cut)
                 const bool ends = (e == bend);
-                if (!started_before && ends) {
-                    LaneModel<Fq>::store(buckets + b, acc);
-                } else if (started_before) {
-                    LaneModel<Fq>::store(out_part + 2 * (uint64_t)t, acc);
+                // ONE store sequence whatever the case (a wave's lanes are in different ones): complete run -> its bucket,
+                // run cut on the left -> HEAD slot, cut on the right only -> TAIL slot
+                G1Acc *dst = (!started_before && ends) ? buckets + b : out_part + 2 * (uint64_t)t + (started_before ? 0u : 1u);
+                if (started_before) {
                     hkey = b;
                     hflag = ends ? FLAG_ENDS : 0u;
-                } else {
-                    LaneModel<Fq>::store(out_part + 2 * (uint64_t)t + 1, acc);
+                } else if (!ends) {
                     tkey = b;
                     tflag = FLAG_STARTS;
                 }
+                LaneModel<Fq>::store(dst, acc);
                 if (e < hi) {                        // next non-empty bucket
-                    do { b++; bend = offsets[b + 1]; } while (bend == e);
+                    b++;
+                    bend = bend2;
+                    while (bend == e) { b++; bend = offsets[b + 1]; }        // empty buckets: rare on uniform scalars
                     started_before = false;
                     acc = XYZZ<FR>::inf();
                 }
@@ -684,20 +701,22 @@ __global__ __launch_bounds__(256) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *
         }
         uint32_t b = bl;
         uint32_t bend = offsets[b + 1];
+        uint32_t bend2 = 0;              // end of the bucket after the current one, as in the G1 kernel
         bool started_before = offsets[b] < lo;
         XYZZ<Fq2s> acc = XYZZ<Fq2s>::inf();
         Fq nextX, nextY;                 // raw words of this lane's component of the next point
         bool nextNeg = false, nextSkip = false;
-        uint32_t entNext = entries[lo];               // two loads deep, as in the G1 kernel
+        uint32_t entNext = entries[lo];               // two loads deep and unconditional, as in the G1 kernel
         auto fetch = [&](uint32_t pos) {
             const uint32_t ent = entNext;
             const uint32_t idx = ent & 0x7fffffffu;
             nextNeg = (ent >> 31) != 0;
             nextSkip = idx < idx_min;
+            bend2 = offsets[b + 2 < nbuckets_total ? b + 2 : nbuckets_total];
             const Fq *src = reinterpret_cast<const Fq *>(points + (nextSkip ? 0 : idx - idx_sub)) + comp;
             nextX = load_el(src);
             nextY = load_el(src + 2);
-            if (pos + 1 < hi) entNext = entries[pos + 1];
+            entNext = entries[pos + 1 < hi ? pos + 1 : hi - 1];
         };
         uint32_t e = lo;
         fetch(e);
@@ -705,7 +724,7 @@ __global__ __launch_bounds__(256) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *
             Fq Xw = nextX, Yw = nextY;
             bool ng = nextNeg, skip = nextSkip;
             e++;
-            if (e < hi) fetch(e);
+            fetch(e < hi ? e : hi - 1);
             if (!skip) {
                 Affine<Fq2s> P{Fq2s{Fq29::load(Xw)}, Fq2s{Fq29::load(Yw)}};
                 if (ng) P.y.v = Fq29::neg_lazy(P.y.v);
@@ -713,19 +732,19 @@ __global__ __launch_bounds__(256) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *
             }
             if (e == bend || e == hi) {
                 const bool ends = (e == bend);
-                if (!started_before && ends) {
-                    store_comp(buckets + b, acc);
-                } else if (started_before) {
-                    store_comp(out_part + 2 * (uint64_t)t, acc);
+                G2Acc *dst = (!started_before && ends) ? buckets + b : out_part + 2 * (uint64_t)t + (started_before ? 0u : 1u);
+                if (started_before) {
                     hkey = b;
                     hflag = ends ? FLAG_ENDS : 0u;
-                } else {
-                    store_comp(out_part + 2 * (uint64_t)t + 1, acc);
+                } else if (!ends) {
                     tkey = b;
                     tflag = FLAG_STARTS;
                 }
+                store_comp(dst, acc);
                 if (e < hi) {
-                    do { b++; bend = offsets[b + 1]; } while (bend == e);
+                    b++;
+                    bend = bend2;
+                    while (bend == e) { b++; bend = offsets[b + 1]; }
                     started_before = false;
                     acc = XYZZ<Fq2s>::inf();
                 }
@@ -1015,7 +1034,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_top(XYZZ<F> 
     if (e < c) LM::store256(final_out + (uint64_t)blockIdx.x * c + e, LM::load(R0 + e));
 }
 static inline bool reduce_bits_for(MsmPlan p) {
-    static const int forced = [] { const char *e = getenv("ZKHIP_REDUCE_BITS"); return e ? atoi(e) : -1; }();
+    static const int forced = [] { const char *e = probe_env("ZKHIP_REDUCE_BITS"); return e ? atoi(e) : -1; }();
     if (p.c > BITS_RS || (uint64_t)p.sets * p.nbuckets > (1u << 16)) return false;      // large sets: work, not depth, counts (2^22 with plain tables: +0.6 %)
     return forced < 0 ? true : forced != 0;
 }
@@ -1027,7 +1046,7 @@ uint32_t msm_wsum_rc(MsmPlan p) { return reduce_bits_for(p) ? p.c : 1u; }
 // what the proof waits for (2^16: 321 us per launch, the largest single item of a proof): smaller chunks
 // there (ZKHIP_REDUCE_CHUNK overrides, tuning aid).
 static inline uint32_t reduce_chunk_for(MsmPlan p) {
-    static const uint32_t forced = [] { const char *e = getenv("ZKHIP_REDUCE_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t forced = [] { const char *e = probe_env("ZKHIP_REDUCE_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t chunk = REDUCE_CHUNK;
     if (forced) chunk = forced;
     else if ((uint64_t)p.sets * p.nbuckets <= (1u << 16)) chunk = 4;
@@ -1180,11 +1199,11 @@ void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, 
 
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
 static inline uint32_t accum_chunk_min() {
-    static const uint32_t cmin = [] { const char *e = getenv("ZKHIP_ACC_CHUNK_MIN"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MIN; return v < 4u ? 4u : v; }();
+    static const uint32_t cmin = [] { const char *e = probe_env("ZKHIP_ACC_CHUNK_MIN"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MIN; return v < 4u ? 4u : v; }();
     return cmin;
 }
 static inline uint32_t accum_chunk_max() {
-    static const uint32_t cmax = [] { const char *e = getenv("ZKHIP_ACC_CHUNK_MAX"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MAX; return v < 8u ? 8u : v; }();
+    static const uint32_t cmax = [] { const char *e = probe_env("ZKHIP_ACC_CHUNK_MAX"); uint32_t v = e ? (uint32_t)atoi(e) : ACC_CHUNK_MAX; return v < 8u ? 8u : v; }();
     return cmax;
 }
 // chunks one round holds: what the occupancy calculator says fits on the device at once (per MSM of a batch)
@@ -1199,7 +1218,7 @@ static uint64_t accum_round_lanes(uint32_t n_msm) {
             else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1<F>, 256, 0);
         }
         if (e != hipSuccess || wgs < 1) { (void)hipGetLastError(); wgs = sizeof(F) == sizeof(Fq2) ? 2 : 3; }
-        if (const char *o = getenv("ZKHIP_ACC_ROUND_WGS")) wgs = atoi(o) > 0 ? atoi(o) : wgs;   // workgroups per CU (probe)
+        if (const char *o = probe_env("ZKHIP_ACC_ROUND_WGS")) wgs = atoi(o) > 0 ? atoi(o) : wgs;   // workgroups per CU (probe)
         return (uint64_t)wgs * 256u * (uint64_t)cus;
     }();
     uint64_t lanes = threads / LaneModel<F>::LPE / (n_msm ? n_msm : 1);
@@ -1269,8 +1288,8 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
     ZK_LAUNCH_OK("msm bucket accumulation");
 }
 
-static uint32_t gather_mask_env() {      // ZKHIP_GATHER_MASK (probe only, WRONG results): confine the G1 table gathers to the low rows
-    static const uint32_t m = [] { const char *e = getenv("ZKHIP_GATHER_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
+static uint32_t gather_mask_env() {      // ZKHIP_GATHER_MASK (-DZK_PROBES builds only, WRONG results): confine the G1 table gathers to the low rows
+    static const uint32_t m = [] { const char *e = probe_env("ZKHIP_GATHER_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
     return m;
 }
 static AccumBatch single(const void *points, uint32_t idx_min, uint32_t idx_sub) {

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "kernels.hpp"
 #include "hipcheck.hpp"
+#include "common.hpp"
 #include "field29.hpp"
 
 namespace zk {
@@ -30,11 +31,11 @@ namespace zk {
 // override, tuning aids).
 #define NTT_MAX_TILE_LOG 11
 static uint32_t ntt_threads() {
-    static const uint32_t v = [] { const char *e = getenv("ZKHIP_NTT_THREADS"); uint32_t t = e ? (uint32_t)atoi(e) : 256u; return t == 512u ? 512u : 256u; }();
+    static const uint32_t v = [] { const char *e = probe_env("ZKHIP_NTT_THREADS"); uint32_t t = e ? (uint32_t)atoi(e) : 256u; return t == 512u ? 512u : 256u; }();
     return v;
 }
 static uint32_t ntt_tile_log() {
-    static const uint32_t v = [] { const char *e = getenv("ZKHIP_NTT_TILE"); uint32_t t = e ? (uint32_t)atoi(e) : 10u; return t < 8u ? 8u : (t > 11u ? 11u : t); }();
+    static const uint32_t v = [] { const char *e = probe_env("ZKHIP_NTT_TILE"); uint32_t t = e ? (uint32_t)atoi(e) : 10u; return t < 8u ? 8u : (t > 11u ? 11u : t); }();
     return v;
 }
 

@@ -470,7 +470,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         // 24.5 -> 23.4 / 21.6 -> 21.6 ms, 8 shards 13.1 -> 12.6 / 10.4 -> 9.6 ms; unsharded it is
         // neutral to slightly negative (2^20: 13.4 -> 13.9 ms single) and stays off.  ZKHIP_S1_PRIO=0/1
         // overrides.
-        const char *e = getenv("ZKHIP_S1_PRIO");
+        const char *e = probe_env("ZKHIP_S1_PRIO");
         const bool s1_hi = e ? atoi(e) != 0 : p->shard_count >= 2;
         if (s1_hi && !getenv("ZKHIP_SERIAL")) {
             int lo_pr = 0, hi_pr = 0;
@@ -707,7 +707,7 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
         if (!pinned) {
             if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes * p->batch, hipHostMallocDefault));
             q.stage[k] = StageJob{q.wtns_pin + (size_t)k * bytes, h_wtns[k], bytes};
-            static const bool sync_stage = getenv("ZKHIP_STAGE_SYNC") != nullptr;      // tuning aid: stage inside the call
+            static const bool sync_stage = probe_env("ZKHIP_STAGE_SYNC") != nullptr;      // tuning aid: stage inside the call
             if (sync_stage) stage_job_run(&q.stage[k]);
             else HIP_TRY(hipLaunchHostFunc(sh, stage_job_run, &q.stage[k]));
             src = q.stage[k].dst;
