@@ -4,7 +4,8 @@
 A "step" is one whole proof (src/groth16.cpp:48-254) of a synthetic BN254 data set with
 n = domainSize = nVars = 2^k (default k = 22: BASELINE configs[2], the largest single-GPU
 configuration and the one the 10x target is quoted on; --log2n 20 gives configs[1]).
-Witnesses are distinct per step and live in HOST memory (pageable numpy arrays), as the
+Every step has its own witness (distinct per step while they fit 8 GiB of host memory: 33 x 128 MiB at
+2^22; `config.distinct_witnesses` says how many were made) in HOST memory (pageable numpy arrays), as the
 reference's Prover::prove(FrElement *wtns) contract has it (src/groth16.hpp:101,
 src/main_prover.cpp:74-75): the upload of every witness is INSIDE the timed region
 (zk_prove_submit stages it through pinned memory on a stream of its own, so that it overlaps
@@ -28,6 +29,12 @@ accumulation k_msm_accum_l1<Fq>, four launches per proof, algorithmic bytes 96*n
 SURVEY §8d; the longest single launch, the G2 accumulation, is reported under `also`) and, at
 N = 1, `cpu_baseline` (the C restatement of rapidsnark's CPU algorithm, oracle/, timed on the
 host cores: one warm-up, then the median of as many full proofs as the budget holds).
+BASELINE's metric is quoted "at 2^20 and 2^22": the default N = 1 run therefore also times the 2^20 member of the
+family (configs[1]) the same way and reports it under `also_2p20` (own ms_per_step, synchronous ms/proof and G1-launch
+roofline fraction; --no-2p20 skips it, and so do --no-cpu and the other non-default workloads: A/B and profiling runs
+want one size).  `ms_per_proof_sync` is SURVEY section 8(d)'s definition of ms/proof: ONE
+synchronous zk_prove with the witness in host memory (the reference's main_prover.cpp:75), next to the pipelined period
+`ms_per_step`.  N > 1 prints `rccl_ranks` and the mean GPU time of each all_to_all / all_gather phase (`exchange_ms`).
 """
 import argparse
 import json
@@ -71,6 +78,7 @@ def parse():
                     help="N > 1: partition the A.w/B.w rows and the NTTs across the ranks (auto: when N is 2, 4 or 8) or replicate them")
     ap.add_argument("--verify", type=int, default=1, help="N > 1: check one sharded proof against an unsharded prover on rank 0 (outside the timed region)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-2p20", action="store_true", help="skip the also_2p20 leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--cpu-budget-s", type=float, default=36.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run")
     return ap.parse_args()
@@ -78,6 +86,24 @@ def parse():
 
 def main():
     args = parse()
+    out = run(args)
+    if out is None:                       # ranks > 0
+        return
+    if args.gpus == 1 and args.log2n == 22 and not args.no_2p20 and not args.no_cpu and args.batch <= 1 and args.witness == "uniform":
+        # BASELINE's metric is quoted "at 2^20 and 2^22": configs[1], timed the same way by the same code
+        import copy
+        a2 = copy.copy(args)
+        a2.log2n, a2.no_cpu, a2.no_2p20, a2.in_flight = 20, True, True, 0
+        o2 = run(a2)
+        out["also_2p20"] = {kk: o2[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "resident_witness",
+                                                   "latency_ms_one_at_a_time", "stage_ms") if kk in o2}
+        r2 = o2["roofline"]
+        out["also_2p20"]["roofline"] = {kk: r2[kk] for kk in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms", "algorithmic_bytes",
+                                                              "launch_ms_one_proof_in_flight", "frac_one_proof_in_flight", "whole_proof")}
+    print(json.dumps(out), flush=True)
+
+
+def run(args):
     if args.batch > 1 and (args.steps % args.batch or args.gpus != 1):
         raise SystemExit("--batch B needs --gpus 1 and --steps a multiple of B")
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # six streams per prover (csrc/prover.hip); read when HIP initialises
@@ -154,7 +180,8 @@ def main():
     # --- distinct witnesses (same on every rank: seeded): pageable host arrays, and HBM copies of
     # the same for the resident-witness leg
     nw = args.steps + args.warmup
-    wits_host = [synth.make_witness(k, seed=i, kind=args.witness) for i in range(min(nw, 4))]   # 4 distinct witnesses cycled (128 MiB each at 2^22)
+    n_wits = max(1, min(nw, (8 << 30) // (32 << k)))      # one per step while they fit 8 GiB of host memory (2^22: all 33), else cycled
+    wits_host = [synth.make_witness(k, seed=i, kind=args.witness) for i in range(n_wits)]
     wits_dev = [torch.from_numpy(w).to(dev) for w in wits_host]
     torch.cuda.synchronize()
     pipelined = bool(args.pipeline)
@@ -334,9 +361,10 @@ def main():
     if dist:
         dist.barrier()
     if rank != 0:
+        prover.lib.zk_prover_destroy(prover.h)
         if dist:
             dist.destroy_process_group()
-        return
+        return None
 
     ms_per_step = elapsed / args.steps * 1e3
     # dominant kernel BY TOTAL TIME: k_msm_accum_l1<Fq> — the G1 bucket accumulation, four launches per
@@ -350,7 +378,9 @@ def main():
               "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
               "witnesses_per_submission": args.batch if (args.batch > 1 and world == 1 and not headline_hbm) else 1,
               "host_threads": 2 if (pipelined and world == 1 and args.collector_thread) else 1,
-              "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)"}
+              "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)",
+              "witness_upload": ("each rank uploads 1/N over PCIe, all_gather over xGMI" if sliced_upload else "whole witness per rank") if world > 1 else "whole witness",
+              "distinct_witnesses": "%d for %d steps + %d warm-up%s" % (len(wits_host), args.steps, args.warmup, "" if len(wits_host) >= nw else " (cycled)")}
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
     pts_per_launch = n / world
     alg_bytes = G1_MSM_BYTES_PER_POINT * pts_per_launch
@@ -391,11 +421,19 @@ def main():
         out["multi_gpu_proof_equals_single_gpu_proof"] = verified
     if latency_ms is not None:
         out["latency_ms_one_at_a_time"] = {"witness_in_hbm": round(latency_ms, 3), "witness_in_host_memory": round(latency_host_ms, 3)}
+        # SURVEY section 8(d)'s ms/proof: one synchronous zk_prove, witness in host RAM, nothing else on the GPU
+        out["ms_per_proof_sync"] = round(latency_host_ms, 3)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, k, synth, prover, wits_host[0], wits_dev[0], args.cpu_budget_s)
-    print(json.dumps(out), flush=True)
+    if world > 1:
+        out["rccl_ranks"] = world
+        out["exchange_backend"] = "gloo via the host (ZK_BENCH_SHARE_GPU test hook)" if share else "nccl (RCCL over xGMI)"
+        if chain is not None:
+            out["exchange_ms"] = chain.phase_times_ms()
+    prover.lib.zk_prover_destroy(prover.h)
     if dist:
         dist.destroy_process_group()
+    return out
 
 
 def default_depth(k, in_hbm, world=1):
@@ -443,6 +481,49 @@ def plan_window_bits(n, world, precomp):
     return max(2, min(16, lg - 6))
 
 
+def view_from_workload(L, wl):
+    """zk_zkey_view over the numpy arrays of a workload dict -> (view, arrays to keep alive until create returns)."""
+    v = L.zk_zkey_view()
+    v.nVars, v.nPublic, v.domainSize, v.nCoefs = wl["nVars"], wl["nPublic"], wl["domainSize"], wl["nCoefs"]
+    keep = []
+    for name in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2", "coefs", "pointsA", "pointsB1",
+                 "pointsB2", "pointsC", "pointsH"):
+        a = np.ascontiguousarray(wl[name])
+        keep.append(a)
+        setattr(v, name, a.ctypes.data)
+        if hasattr(v, name + "_bytes"):
+            setattr(v, name + "_bytes", a.size)
+    return v, keep
+
+
+class MultiProverFromView:
+    """zk_multi_prover (ONE proof over several devices of this process, chain partitioned for 2/4/8) over an in-memory view."""
+
+    def __init__(self, zk, wl, devices, precomp=False):
+        import ctypes as C
+        from rapidsnark_old_amd import lib as L
+        self.L, self.C, self.lib = L, C, L.load_library()
+        v, keep = view_from_workload(L, wl)
+        devs = (C.c_int32 * len(devices))(*devices)
+        o = L.zk_opts(-1, 0, 1, 0, L.ZK_FLAG_PRECOMP if precomp else 0)
+        self.h = C.c_void_p()
+        L.check(self.lib.zk_multi_prover_create(C.byref(self.h), C.byref(v), devs, len(devices), C.byref(o)))
+        ns, part = C.c_uint32(), C.c_uint32()
+        L.check(self.lib.zk_multi_prover_info(self.h, C.byref(ns), C.byref(part)))
+        self.n_shards, self.chain_partitioned = ns.value, bool(part.value)
+
+    def prove(self, w, r, s):
+        out = self.L.zk_proof()
+        ra, sa = ProverFromView._k32(r), ProverFromView._k32(s)
+        self.L.check(self.lib.zk_multi_prove(self.h, self.C.c_void_p(w.ctypes.data), ra.ctypes.data, sa.ctypes.data, self.C.byref(out)))
+        return bytes(out)
+
+    def close(self):
+        if self.h.value:
+            self.lib.zk_multi_prover_destroy(self.h)
+            self.h = self.C.c_void_p()
+
+
 class ProverFromView:
     """zk.Prover over an in-memory view (numpy arrays) instead of a .zkey file."""
 
@@ -451,16 +532,7 @@ class ProverFromView:
         from rapidsnark_old_amd import lib as L
         self.L = L
         self.lib = L.load_library()
-        v = L.zk_zkey_view()
-        v.nVars, v.nPublic, v.domainSize, v.nCoefs = wl["nVars"], wl["nPublic"], wl["domainSize"], wl["nCoefs"]
-        self.keep = []
-        for name in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2", "coefs", "pointsA", "pointsB1",
-                     "pointsB2", "pointsC", "pointsH"):
-            a = np.ascontiguousarray(wl[name])
-            self.keep.append(a)
-            setattr(v, name, a.ctypes.data)
-            if hasattr(v, name + "_bytes"):
-                setattr(v, name + "_bytes", a.size)
+        v, self.keep = view_from_workload(L, wl)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
                       (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
                       | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0), batch)
@@ -585,7 +657,9 @@ def cpu_baseline(wl, k, synth, prover, w0, w0_dev, budget_s):
     est_full = t_probe * (1 << (k - kp)) * 1.15
     r, s = 0x1234567, 0x7654321
     note = ("C restatement of rapidsnark's CPU algorithm (oracle/c/zk_oracle.c), gcc -O3 -march=native -fopenmp; "
-            "NOT ffiasm: hand-written ADX assembly may be 1.3-2x faster")
+            "NOT ffiasm: hand-written ADX assembly may be 1.3-2x faster.  Parity unpinned at the reference boundary: the "
+            "reference ships no vectors and cannot be built in this image (DESIGN.md section 2), so 'bit-exact' below means "
+            "against this restatement, itself pinned by the trapdoor check and third-party vectors only")
     if est_full <= budget_s * 1.5:
         view = co.ZkeyView(wl)
         times, proof_cpu = [], None

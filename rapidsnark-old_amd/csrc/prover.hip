@@ -18,6 +18,7 @@
 #include <thread>
 #include <memory>
 #include <stdexcept>
+#include <exception>
 
 #include "../../include/zkhip.h"
 #include "common.hpp"
@@ -271,6 +272,17 @@ struct zk_prover {
         hipStream_t stream = nullptr, stream2 = nullptr;
         DevBuf<Fr> abc, h;
         SortBufs sort_h;
+        // the buffers (~1 GiB per lane at 2^22) appear the first time a proof runs on the lane, like the proof slots: the
+        // one-shot CLI and the shards of a sharded proof never use more than lane 0
+        uint64_t n_abc = 0, n_h = 0, nh_sort = 0;
+        uint32_t wbits = 0, batch = 1;
+        bool precomp = false;
+        void ensure() {
+            if (abc.p) return;
+            abc.alloc(n_abc);
+            h.alloc(n_h);
+            sort_h.alloc(nh_sort, wbits, precomp, batch);
+        }
         ~LaneExtra() {
             if (stream2 && stream2 != stream) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
             if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
@@ -647,9 +659,12 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             const bool one_stream = ls && atoi(ls) == 1;
             if (one_stream) x->stream2 = x->stream;
             else HIP_TRY(hipStreamCreateWithFlags(&x->stream2, hipStreamNonBlocking));
-            x->abc.alloc(3 * p->nloc * p->batch);
-            x->h.alloc(p->nloc * p->batch);
-            x->sort_h.alloc(nh, wbits, p->precomp, p->batch);
+            x->n_abc = 3 * p->nloc * p->batch;
+            x->n_h = p->nloc * p->batch;
+            x->nh_sort = nh;
+            x->wbits = wbits;
+            x->precomp = p->precomp;
+            x->batch = p->batch;
             p->extra[l - 1] = std::move(x);
         }
         p->lanes = lanes;
@@ -759,6 +774,7 @@ struct PhaseCtx {
             abc = p->abc_use; h = p->h.p; sort_h = &p->sort_h;
         } else {
             zk_prover::LaneExtra &x = *p->extra[lane - 1];
+            x.ensure();
             s = x.stream; s2 = x.stream2; sf = x.stream;
             abc = x.abc.p; h = x.h.p; sort_h = &x.sort_h;
         }
@@ -1080,6 +1096,14 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
         std::lock_guard<std::mutex> lk(p->mtx);
         if (!p->in_flight) throw std::invalid_argument("no proof in flight");
         qp = &p->slot[p->next_collect % ZK_MAX_IN_FLIGHT];
+        // a call that cannot take THIS submission is refused BEFORE anything is retired: the submission stays the oldest
+        // one and the caller's FIFO stays in step (a wrong count used to drop every proof of the submission)
+        if (p->batch > 1) {
+            if (!direct) throw std::invalid_argument("partial sums are not available from a batch prover");
+            if (direct->count != qp->count) throw std::invalid_argument("this submission carries a different number of proofs");
+        } else if (direct && direct->count != 1) {
+            throw std::invalid_argument("this prover was not created for batched submissions");
+        }
     }
     zk_prover::ProofSlot &q = *qp;
     DeviceGuard g(p->device);
@@ -1135,8 +1159,7 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     const size_t P1 = sizeof(G1XYZZ);
     const uint8_t *w1 = q.w1, *w2 = q.w2;
     if (direct && p->batch > 1) {
-        // one bucket set per proof of the submission: records [msm][proof][rc]
-        if (direct->count != q.count) throw std::invalid_argument("this submission carries a different number of proofs");
+        // one bucket set per proof of the submission: records [msm][proof][rc]  (count checked before the wait)
         const size_t Rw = (size_t)rcw * sizeof(G1XYZZ), Rh = (size_t)rch * sizeof(G1XYZZ), R2 = (size_t)rcw * sizeof(G2XYZZ);
         for (uint32_t k = 0; k < q.count; k++) {
             const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[k] : nullptr) : direct->r32;
@@ -1148,7 +1171,6 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
         }
         return;
     }
-    if (p->batch > 1) throw std::invalid_argument("partial sums are not available from a batch prover");
     if (direct) {
         const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[0] : nullptr) : direct->r32;
         const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[0] : nullptr) : direct->s32;
@@ -1392,7 +1414,18 @@ void multi_create(zk_multi_prover **out, const zk_zkey_view *z, const int32_t *d
     while ((1u << lg) < nd) lg++;
     uint32_t logn = 0;
     while ((1ull << logn) < z->domainSize) logn++;
-    const bool can_part = nd > 1 && (1u << lg) == nd && logn >= 2 * lg && !getenv("ZKHIP_REPLICATED_CHAIN");
+    bool can_part = nd > 1 && (1u << lg) == nd && logn >= 2 * lg && !getenv("ZKHIP_REPLICATED_CHAIN");
+    // the partitioned chain writes into its peers' buffers: every pair of distinct devices must be able to map each other
+    // (xGMI inside a node).  Where one cannot, the chain stays replicated (partial sums only travel through the host).
+    bool peers_ok = true;
+    for (uint32_t a = 0; a < nd && peers_ok; a++)
+        for (uint32_t b = 0; b < nd && peers_ok; b++) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, devices[a], devices[b]));
+            if (!can) peers_ok = false;
+        }
+    if (!peers_ok) can_part = false;
     mp->part = can_part;
     for (uint32_t g = 0; g < nd; g++) {
         zk_opts so;
@@ -1407,8 +1440,8 @@ void multi_create(zk_multi_prover **out, const zk_zkey_view *z, const int32_t *d
         prover_create(&q, z, &so);
         mp->shard.push_back(q);
     }
-    // peer access between every pair of distinct devices (xGMI inside a node)
-    for (uint32_t a = 0; a < nd; a++)
+    // peer access between every pair of distinct devices (xGMI inside a node); only the partitioned chain needs it
+    for (uint32_t a = 0; a < nd && can_part; a++)
         for (uint32_t b = 0; b < nd; b++) {
             if (devices[a] == devices[b]) continue;
             DeviceGuard g(devices[a]);
@@ -1505,7 +1538,17 @@ void multi_collect(zk_multi_prover *mp, zk_proof *out) {
     const size_t G = mp->shard.size();
     std::vector<zk_msm_sums> sums(G);
     SubmittedRS rs;
-    for (size_t a = 0; a < G; a++) collect_sums(mp->shard[a], &sums[a], a == 0 ? &rs : nullptr);
+    // EVERY shard's oldest submission is retired, whatever one of them throws: a shard left behind would pair its partial
+    // sums with the next proof's on every later collect
+    std::exception_ptr first;
+    for (size_t a = 0; a < G; a++) {
+        try {
+            collect_sums(mp->shard[a], &sums[a], a == 0 ? &rs : nullptr);
+        } catch (...) {
+            if (!first) first = std::current_exception();
+        }
+    }
+    if (first) std::rethrow_exception(first);
     prove_finish(mp->shard[0], sums.data(), (uint32_t)G, rs.have_r ? rs.r32 : nullptr, rs.have_s ? rs.s32 : nullptr, out);
 }
 

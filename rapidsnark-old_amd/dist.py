@@ -42,6 +42,33 @@ class ShardedChain:
         self.recv = torch.zeros(3 * self.nloc * 32, dtype=torch.uint8, device=device)
         L.check(lib.zk_shard_set_exchange(handle, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr())))
         self.exchange = exchange or self._all_to_all
+        self._phase_events = []          # per proof: five (start, end) CUDA event pairs around the exchanges (self-diagnosing SCALE runs)
+        self.time_phases = device.type == "cuda"
+
+    PHASES = ("witness_all_gather", "all_to_all_1_to_cross_inverse", "all_to_all_2_to_local", "all_to_all_3_to_cross_forward", "all_to_all_4_to_finish")
+
+    def _timed(self, slot, fn, *a):
+        if not self.time_phases:
+            return fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a)
+        e1.record()
+        self._cur[slot] = (e0, e1)
+        return r
+
+    def phase_times_ms(self):
+        """Mean GPU time of every exchange phase over the proofs submitted so far (includes waiting for the slowest peer:
+        the collective cannot start before every rank has enqueued it)."""
+        torch.cuda.synchronize()
+        acc, cnt = [0.0] * len(self.PHASES), [0] * len(self.PHASES)
+        for ev in self._phase_events:
+            for i, pair in enumerate(ev):
+                if pair is not None:
+                    acc[i] += pair[0].elapsed_time(pair[1])
+                    cnt[i] += 1
+        self._phase_events = []
+        return {name: round(acc[i] / cnt[i], 4) for i, name in enumerate(self.PHASES) if cnt[i]}
 
     def _all_to_all(self, dst, src):
         self.dist.all_to_all_single(dst, src)
@@ -71,13 +98,16 @@ class ShardedChain:
         lo, hi = self._sl
         self._wpin[k].copy_(torch.from_numpy(wtns[lo:hi]))            # pageable -> pinned, 1/world of the witness
         self._wpart[k].copy_(self._wpin[k], non_blocking=True)        # PCIe, on the current stream
-        self._gather(self._wfull[k], self._wpart[k])                  # xGMI
-        self.submit(d_wtns=self._wfull[k].data_ptr(), r=r, s=s)
+        self._cur = [None] * len(self.PHASES)
+        self._timed(0, self._gather, self._wfull[k], self._wpart[k])  # xGMI
+        self.submit(d_wtns=self._wfull[k].data_ptr(), r=r, s=s, _keep_cur=True)
 
-    def submit(self, wtns=None, d_wtns=None, r=None, s=None):
+    def submit(self, wtns=None, d_wtns=None, r=None, s=None, _keep_cur=False):
         """Enqueue one proof: wtns = host numpy uint8 array (kept alive by the caller until collected) or
         d_wtns = device pointer."""
         C, L = self.C, self.L
+        if not _keep_cur:
+            self._cur = [None] * len(self.PHASES)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ra = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8) if r is not None else None
         sa = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8) if s is not None else None
@@ -85,11 +115,15 @@ class ShardedChain:
                                         C.c_void_p(d_wtns) if d_wtns is not None else None,
                                         C.c_void_p(ra.ctypes.data) if ra is not None else None,
                                         C.c_void_p(sa.ctypes.data) if sa is not None else None, stream))
-        self.exchange(self.recv, self.send)
+        self._timed(1, self.exchange, self.recv, self.send)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_CROSS_INVERSE, stream))
-        self.exchange(self.send, self.recv)
+        self._timed(2, self.exchange, self.send, self.recv)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_LOCAL, stream))
-        self.exchange(self.recv, self.send)
+        self._timed(3, self.exchange, self.recv, self.send)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_CROSS_FORWARD, stream))
-        self.exchange(self.send, self.recv)
+        self._timed(4, self.exchange, self.send, self.recv)
         L.check(self.lib.zk_shard_step(self.h, L.ZK_STEP_FINISH, stream))
+        if self.time_phases:
+            self._phase_events.append(self._cur)
+            if len(self._phase_events) > 256:
+                self._phase_events.pop(0)

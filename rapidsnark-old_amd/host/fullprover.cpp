@@ -1,5 +1,6 @@
 #include "fullprover.hpp"
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,10 +143,24 @@ void FullProver::generateWitness(Job &job, const std::string &tag) {
     const std::string base = "./build/";
     const std::string inputFile = base + "input_" + job.circuit + tag + ".json";
     const std::string witnessFile = base + job.circuit + tag + ".wtns";
+    // concurrent jobs (tag non-empty): the per-job files go away on EVERY path out of here — the mapping keeps a good
+    // witness alive, a failing generator / bad header / nVars mismatch must not leave files in ./build
+    struct Cleanup {
+        const std::string &a, &b;
+        bool on;
+        ~Cleanup() {
+            if (on) {
+                std::remove(a.c_str());
+                std::remove(b.c_str());
+            }
+        }
+    } cleanup{inputFile, witnessFile, !tag.empty()};
     {
         std::ofstream f(inputFile);
         f << job.input;
     }
+    // the body (up to 128 MB) is on disk now: a job stays in the `jobs` map long after it is done, its request body must not
+    std::string().swap(job.input);
     std::string output;
     const int waitStatus = runGenerator(base + job.circuit, inputFile, witnessFile, output);
     std::cout << output << std::endl;
@@ -154,19 +169,18 @@ void FullProver::generateWitness(Job &job, const std::string &tag) {
         throw std::runtime_error("witness generator failed with code " + std::to_string(WIFEXITED(waitStatus) ? WEXITSTATUS(waitStatus) : waitStatus));
 
     job.wtns = BinFileUtils::openExisting(witnessFile, "wtns", 2);
+    adoptWitness(job, known->second.header.get());
+}
+
+void FullProver::adoptWitness(Job &job, const ZKeyUtils::Header *zh) {
     auto wh = WtnsUtils::loadHeader(job.wtns.get());
     if (memcmp(wh->prime.data(), kBn254Order, 32) != 0) throw std::invalid_argument("different wtns curve");
-    const ZKeyUtils::Header *zh = known->second.header.get();
     if (wh->nVars != zh->nVars || job.wtns->getSectionSize(2) < (uint64_t)zh->nVars * 32)
         throw std::invalid_argument("witness does not match the zkey (nVars)");
     job.wtnsData = static_cast<const uint8_t *>(job.wtns->getSectionData(2));
     std::string pub(zk_public_to_json(job.wtnsData, zh->nPublic, nullptr, 0), '\0');
     zk_public_to_json(job.wtnsData, zh->nPublic, pub.data(), pub.size() + 1);
     job.pubData = pub;
-    if (!tag.empty()) {      // concurrent jobs: the mapping keeps the witness alive, the names can go
-        std::remove(inputFile.c_str());
-        std::remove(witnessFile.c_str());
-    }
 }
 
 // ------------------------------------------------------------------ single-slot mode (the reference's)
@@ -216,13 +230,16 @@ void FullProver::runSingle(JobPtr job) {
 
 void FullProver::abort() {
     std::lock_guard<std::mutex> guard(mtx);
-    if (queueMode()) {           // cancels everything that has not reached a GPU yet
-        for (auto &j : incoming) {
-            j->status = aborted;
-            j->canceled = true;
+    if (queueMode()) {           // cancels everything that has not reached a GPU yet: waiting for a generator, or ready for a dispatcher
+        for (auto *q : {&incoming, &readyJobs}) {
+            for (auto &j : *q) {
+                j->status = aborted;
+                j->canceled = true;
+                j->wtns.reset();
+            }
+            q->clear();
         }
-        incoming.clear();
-        return;
+        return;                  // (a job inside its generator right now finishes it and is dropped in witnessLoop)
     }
     if (status == busy && executing) executing->canceled = true;
 }
@@ -254,7 +271,9 @@ std::string FullProver::getStatus() {
 // ------------------------------------------------------------------ throughput mode
 bool FullProver::enqueue(std::string input, std::string circuit, uint64_t &id) {
     std::lock_guard<std::mutex> guard(mtx);
-    if (incoming.size() >= queueCap) return false;
+    // everything that has not reached a GPU counts: waiting for a generator, inside one, or ready for a dispatcher (each
+    // ready job holds a mapped witness image) — the 503 must fire when the GPUs are the slow side too
+    if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
     JobPtr j = std::make_shared<Job>();
     j->id = id = nextId++;
     j->input = std::move(input);
@@ -262,6 +281,34 @@ bool FullProver::enqueue(std::string input, std::string circuit, uint64_t &id) {
     incoming.push_back(j);
     remember(j);
     cvIncoming.notify_one();
+    return true;
+}
+
+bool FullProver::enqueueWitness(std::string wtnsImage, std::string circuit, uint64_t &id) {
+    JobPtr j = std::make_shared<Job>();
+    j->circuit = std::move(circuit);
+    j->haveImage = true;
+    std::string error;
+    try {        // parsed on the HTTP thread that received it: nothing here needs the prover's lock
+        auto known = circuits.find(j->circuit);
+        if (known == circuits.end()) throw std::runtime_error("unknown circuit: " + j->circuit);
+        j->wtns = BinFileUtils::fromMemory(std::move(wtnsImage), "wtns", 2);
+        adoptWitness(*j, known->second.header.get());
+    } catch (std::exception &e) {
+        error = e.what();
+    }
+    std::lock_guard<std::mutex> guard(mtx);
+    if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
+    j->id = id = nextId++;
+    remember(j);
+    if (!error.empty()) {
+        j->wtns.reset();
+        j->error = error;
+        j->status = failed;
+        return true;
+    }
+    readyJobs.push_back(j);
+    cvReady.notify_one();
     return true;
 }
 
@@ -287,6 +334,7 @@ void FullProver::witnessLoop() {
             if (stopping) return;
             job = incoming.front();
             incoming.pop_front();
+            inWitness++;
         }
         std::string error;
         try {
@@ -295,6 +343,12 @@ void FullProver::witnessLoop() {
             error = e.what();
         }
         std::lock_guard<std::mutex> guard(mtx);
+        inWitness--;
+        if (job->canceled) {             // /cancel arrived while the generator ran
+            job->wtns.reset();
+            job->status = aborted;
+            continue;
+        }
         if (!error.empty()) {
             job->wtns.reset();
             job->error = error;

@@ -42,6 +42,9 @@ public:
     // throughput mode
     bool queueMode() const { return queueCap > 0; }
     bool enqueue(std::string input, std::string circuit, uint64_t &id);   // false: queue full
+    // POST /witness/:circuit — the witness arrives as a .wtns image in the request body (a generator running inside the
+    // caller, or another host): no generator process, no files; everything else is the same job
+    bool enqueueWitness(std::string wtnsImage, std::string circuit, uint64_t &id);
     std::string getStatus(uint64_t id);                                    // GET /status/<id>
 
 private:
@@ -59,6 +62,7 @@ private:
         std::unique_ptr<BinFileUtils::BinFile> wtns;   // the witness image stays mapped until the proof is collected
         const uint8_t *wtnsData = nullptr;
         bool canceled = false;
+        bool haveImage = false;                        // `input` holds a .wtns image, not circom input JSON
     };
     typedef std::shared_ptr<Job> JobPtr;
 
@@ -76,10 +80,12 @@ private:
 
     // throughput mode
     std::deque<JobPtr> incoming, readyJobs;
+    size_t inWitness = 0;                      // jobs inside a witness generator right now (count against queueCap)
     std::map<uint64_t, JobPtr> jobs;           // recent jobs by id (bounded)
     std::vector<std::thread> threads;
 
     void generateWitness(Job &job, const std::string &tag);   // throws; fills job.wtns / wtnsData / pubData
+    void adoptWitness(Job &job, const ZKeyUtils::Header *zh); // the checks + public signals once job.wtns is open
     static std::string statusDocument(const Job &job);
     void remember(const JobPtr &job);          // caller holds mtx
     void checkPending();                       // caller holds mtx

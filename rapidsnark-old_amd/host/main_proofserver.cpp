@@ -1,13 +1,19 @@
 // proverServer <port> <circuit1.zkey> ... <circuitN.zkey>
-// The REST shell of the reference (src/main_proofserver.cpp:11-45, src/proverapi.cpp:9-41) over a
-// self-contained single-threaded HTTP/1.1 loop (the reference's Pistache is an empty submodule):
+// The REST shell of the reference (src/main_proofserver.cpp:11-45, src/proverapi.cpp:9-41) over a self-contained
+// HTTP/1.1 front end (the reference's Pistache is an empty submodule):
 //   GET  /status            -> FullProver::getStatus() document, application/json
 //   POST /input/:circuit    -> body = circom input JSON; 200 at once, job runs in the background
 //   POST /cancel            -> abort()
 //   POST /start, /stop      -> 200, no-ops (proverapi.cpp:27-33)
-// Throughput mode (ZKHIP_QUEUE=n, see fullprover.hpp): POST /input/:circuit answers {"job":id} (503 when n
-// requests are already waiting) and GET /status/<id> reports that job; everything else is unchanged.
-// One HTTP thread, bodies up to 128000000 bytes (main_proofserver.cpp:32).
+// Throughput mode (ZKHIP_QUEUE=n, see fullprover.hpp): POST /input/:circuit answers {"job":id} (503 when n requests
+// are already waiting), GET /status/<id> reports that job, and POST /witness/:circuit takes the witness itself
+// (a .wtns image as the body) instead of running the generator; everything else is unchanged.
+// The reference runs ONE HTTP thread (Http::Endpoint::options().threads(1), main_proofserver.cpp:34) and one request
+// per connection; behind eight GPUs that loop is the bound (round-2 measurement: 2018 proofs/s through REST against
+// 3300 through the C-ABI at 2^14).  Here ZKHIP_HTTP_THREADS workers (default 8) all accept on the listening socket
+// and serve their connection with keep-alive (requests back to back until the client closes or is idle for 5 s), so
+// parsing a body, answering status polls and enqueueing jobs happen on different cores.  Bodies up to 128000000
+// bytes (main_proofserver.cpp:32).
 #include <arpa/inet.h>
 #include <cerrno>
 #include <csignal>
@@ -15,8 +21,12 @@
 #include <iostream>
 #include <netinet/in.h>
 #include <string>
+#include <netinet/tcp.h>
 #include <sys/socket.h>
+#include <sys/time.h>
+#include <thread>
 #include <unistd.h>
+#include <vector>
 
 #include "fullprover.hpp"
 
@@ -32,11 +42,15 @@ static bool send_all(int fd, const std::string &s) {
     return true;
 }
 
+// per connection: does the client want it kept open after this response?
+static thread_local bool t_keep = false;
+
 static void respond(int fd, int code, const char *reason, const std::string &body, const char *ctype) {
+    if (code >= 400 && code != 404 && code != 503) t_keep = false;      // malformed / oversized requests end the connection
     std::string h = "HTTP/1.1 " + std::to_string(code) + " " + reason + "\r\n";
     if (ctype) h += std::string("Content-Type: ") + ctype + "\r\n";
-    h += "Content-Length: " + std::to_string(body.size()) + "\r\nConnection: close\r\n\r\n";
-    send_all(fd, h + body);
+    h += "Content-Length: " + std::to_string(body.size()) + (t_keep ? "\r\nConnection: keep-alive\r\n\r\n" : "\r\nConnection: close\r\n\r\n");
+    if (!send_all(fd, h + body)) t_keep = false;
 }
 
 static std::string lower(std::string s) {
@@ -44,13 +58,15 @@ static std::string lower(std::string s) {
     return s;
 }
 
-static void handle(int fd, FullProver &fp) {
-    std::string buf;
-    size_t hdr_end = std::string::npos;
+// One request of a connection.  `buf` carries bytes already received beyond the previous request (a client may send the
+// next request before it has read the answer).  Sets t_keep; a closed / idle / broken connection clears it.
+static void handle(int fd, FullProver &fp, std::string &buf) {
+    t_keep = false;
+    size_t hdr_end = buf.find("\r\n\r\n");
     char tmp[65536];
     while (hdr_end == std::string::npos) {
         ssize_t k = ::recv(fd, tmp, sizeof tmp, 0);
-        if (k <= 0) return;
+        if (k <= 0) return;                      // closed, or idle for longer than the receive timeout
         buf.append(tmp, (size_t)k);
         hdr_end = buf.find("\r\n\r\n");
         if (hdr_end == std::string::npos && buf.size() > 65536) return respond(fd, 431, "Request Header Fields Too Large", "", nullptr);
@@ -66,6 +82,8 @@ static void handle(int fd, FullProver &fp) {
 
     size_t clen = 0;
     bool expect100 = false;
+    const bool http11 = reqline.size() >= 8 && reqline.compare(reqline.size() - 8, 8, "HTTP/1.1") == 0;
+    bool keep = http11;                          // HTTP/1.1: persistent unless the client says close; 1.0: the other way round
     size_t pos = le == std::string::npos ? head.size() : le + 2;
     while (pos < head.size()) {
         size_t e = head.find("\r\n", pos);
@@ -77,6 +95,7 @@ static void handle(int fd, FullProver &fp) {
             while (!val.empty() && val[0] == ' ') val.erase(0, 1);
             if (key == "content-length") clen = (size_t)strtoull(val.c_str(), nullptr, 10);
             if (key == "expect" && lower(val) == "100-continue") expect100 = true;
+            if (key == "connection") keep = lower(val) == "keep-alive" ? true : (lower(val) == "close" ? false : keep);
         }
         pos = e + 2;
     }
@@ -88,7 +107,9 @@ static void handle(int fd, FullProver &fp) {
         if (k <= 0) return;
         body.append(tmp, (size_t)k);
     }
+    buf = body.size() > clen ? body.substr(clen) : std::string();      // the start of the next request, if any
     body.resize(clen);
+    t_keep = keep;
 
     if (method == "GET" && target == "/status") return respond(fd, 200, "OK", fp.getStatus(), "application/json");
     if (method == "GET" && fp.queueMode() && target.rfind("/status/", 0) == 0 && target.size() > 8) {   // throughput mode: one job's document
@@ -101,6 +122,11 @@ static void handle(int fd, FullProver &fp) {
     if (method == "POST" && target == "/cancel") {
         fp.abort();
         return respond(fd, 200, "OK", "", nullptr);
+    }
+    if (method == "POST" && fp.queueMode() && target.rfind("/witness/", 0) == 0 && target.size() > 9 && target.find('/', 9) == std::string::npos) {
+        uint64_t id = 0;                         // the witness itself (.wtns image): no generator process, no files
+        if (!fp.enqueueWitness(std::move(body), target.substr(9), id)) return respond(fd, 503, "Service Unavailable", "{\"error\":\"queue full\"}", "application/json");
+        return respond(fd, 200, "OK", "{\"job\":" + std::to_string(id) + "}", "application/json");
     }
     if (method == "POST" && target.rfind("/input/", 0) == 0 && target.size() > 7 && target.find('/', 7) == std::string::npos) {
         if (fp.queueMode()) {      // ZKHIP_QUEUE=n: requests queue up instead of replacing each other
@@ -138,17 +164,35 @@ int main(int argc, char **argv) {
         addr.sin_addr.s_addr = htonl(INADDR_ANY);
         addr.sin_port = htons((uint16_t)port);
         if (::bind(ls, (sockaddr *)&addr, sizeof addr) < 0) throw std::runtime_error(std::string("bind: ") + strerror(errno));
-        if (::listen(ls, 64) < 0) throw std::runtime_error(std::string("listen: ") + strerror(errno));
+        if (::listen(ls, 1024) < 0) throw std::runtime_error(std::string("listen: ") + strerror(errno));
+        size_t nthreads = 8;
+        if (const char *e = getenv("ZKHIP_HTTP_THREADS")) nthreads = (size_t)strtoul(e, nullptr, 10);
+        if (nthreads < 1) nthreads = 1;
+        if (nthreads > 256) nthreads = 256;
         std::cerr << "Server ready on port " << port << "...\n";
-        for (;;) {   // one HTTP thread, like Http::Endpoint::options().threads(1)
-            int fd = ::accept(ls, nullptr, nullptr);
-            if (fd < 0) {
-                if (errno == EINTR) continue;
-                throw std::runtime_error(std::string("accept: ") + strerror(errno));
+        auto worker = [&] {
+            for (;;) {
+                int fd = ::accept(ls, nullptr, nullptr);
+                if (fd < 0) {
+                    if (errno == EINTR || errno == ECONNABORTED) continue;
+                    std::cerr << "accept: " << strerror(errno) << '\n';
+                    return;
+                }
+                int on = 1;
+                setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &on, sizeof on);
+                timeval idle{5, 0};              // a kept-alive connection that stays silent gives its worker back
+                setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &idle, sizeof idle);
+                std::string carry;
+                do {
+                    handle(fd, fullProver, carry);
+                } while (t_keep);
+                ::close(fd);
             }
-            handle(fd, fullProver);
-            ::close(fd);
-        }
+        };
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < nthreads; i++) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
     } catch (std::exception &e) {
         std::cerr << e.what() << '\n';
         return -1;

@@ -40,7 +40,16 @@ BinFile::BinFile(const std::string &fileName, const std::string &type, uint32_t 
         map_ = static_cast<uint8_t *>(m);
     }
     close(fd);
+    indexSections(type, maxVersion);
+}
 
+BinFile::BinFile(std::string &&image, const std::string &type, uint32_t maxVersion) : owned_(std::move(image)) {
+    map_ = reinterpret_cast<uint8_t *>(owned_.data());
+    mapLen_ = owned_.size();
+    indexSections(type, maxVersion);
+}
+
+void BinFile::indexSections(const std::string &type, uint32_t maxVersion) {
     // preamble: 4-byte magic, u32 version, u32 section count
     const std::string magic(reinterpret_cast<const char *>(take(4)), 4);
     if (magic != type) throw std::invalid_argument("Invalid file type. It should be " + type + " and it us " + magic);
@@ -59,7 +68,7 @@ BinFile::BinFile(const std::string &fileName, const std::string &type, uint32_t 
 }
 
 BinFile::~BinFile() {
-    if (map_) munmap(map_, mapLen_);
+    if (map_ && owned_.empty()) munmap(map_, mapLen_);
 }
 
 const uint8_t *BinFile::take(uint64_t len) {
@@ -101,6 +110,9 @@ uint64_t BinFile::getSectionSize(uint32_t sectionId, uint32_t sectionPos) { retu
 
 std::unique_ptr<BinFile> openExisting(const std::string &filename, const std::string &type, uint32_t maxVersion) {
     return std::make_unique<BinFile>(filename, type, maxVersion);
+}
+std::unique_ptr<BinFile> fromMemory(std::string &&image, const std::string &type, uint32_t maxVersion) {
+    return std::make_unique<BinFile>(std::move(image), type, maxVersion);
 }
 
 }   // namespace BinFileUtils

@@ -24,6 +24,8 @@ namespace BinFileUtils {
 class BinFile {
 public:
     BinFile(const std::string &fileName, const std::string &type, uint32_t maxVersion);
+    // the same container held in memory (a .wtns image that arrived in a request body): the image is owned by the object
+    BinFile(std::string &&image, const std::string &type, uint32_t maxVersion);
     ~BinFile();
     BinFile(const BinFile &) = delete;
     BinFile &operator=(const BinFile &) = delete;
@@ -46,14 +48,17 @@ private:
     const Extent &extent(uint32_t id, uint32_t nth) const;
     const uint8_t *take(uint64_t len);   // advance the cursor, checked
 
+    void indexSections(const std::string &type, uint32_t maxVersion);
     uint8_t *map_ = nullptr;
     uint64_t mapLen_ = 0;
+    std::string owned_;                  // in-memory images (map_ points into it; nothing to unmap)
     uint64_t cursor_ = 0;
     std::map<uint32_t, std::vector<Extent>> index_;
     const Extent *open_ = nullptr;
 };
 
 std::unique_ptr<BinFile> openExisting(const std::string &filename, const std::string &type, uint32_t maxVersion);
+std::unique_ptr<BinFile> fromMemory(std::string &&image, const std::string &type, uint32_t maxVersion);
 
 }   // namespace BinFileUtils
 

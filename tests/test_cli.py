@@ -95,3 +95,35 @@ def test_cli_over_several_devices(tmp_path, devices):
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "p.json").read_bytes() == golden_bytes(name, "proof.json")
     assert (tmp_path / "q.json").read_bytes() == golden_bytes(name, "public.json")
+
+
+# Every environment variable INTEGRATION.md section 5 documents for the library / CLI, with a non-default value: none of them
+# may change the proof.  The retired measurement probes (compiled out of the shipped library: -DZK_PROBES) are set too —
+# ZKHIP_GATHER_MASK used to give WRONG proofs with exit code 0; in the default build it must have no effect at all.
+_DOCUMENTED = [{"ZKHIP_VERBOSE": "1"}, {"ZKHIP_SERIAL": "1"}, {"ZKHIP_PRECOMP": "1"}, {"ZKHIP_PRECOMP": "0"}, {"ZKHIP_DEVICE": "0"},
+               {"ZKHIP_LANES": "1"}, {"ZKHIP_LANES": "3", "ZKHIP_LANE_STREAMS": "1"}, {"ZKHIP_TAIL": "0"}, {"ZKHIP_TAIL": "2"},
+               {"ZKHIP_GRAPH": "1"}, {"ZKHIP_BATCH_ABC": "0"}, {"ZKHIP_BATCH_ABC": "1", "ZKHIP_PRECOMP": "1"},
+               {"ZKHIP_DEVICES": "0,0,0,0", "ZKHIP_REPLICATED_CHAIN": "1"}, {"GPU_MAX_HW_QUEUES": "8"}]
+_RETIRED_PROBES = {"ZKHIP_GATHER_MASK": "0xff", "ZKHIP_ACC_ROUND_WGS": "1", "ZKHIP_ACC_CHUNK_MIN": "4", "ZKHIP_ACC_CHUNK_MAX": "8",
+                   "ZKHIP_STAGE_SYNC": "1", "ZKHIP_NTT_THREADS": "512", "ZKHIP_NTT_TILE": "8", "ZKHIP_REDUCE_BITS": "0",
+                   "ZKHIP_REDUCE_CHUNK": "2", "ZKHIP_S1_PRIO": "1"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", _DOCUMENTED + [_RETIRED_PROBES], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items()))[:60])
+def test_environment_switches_never_change_the_proof(tmp_path, extra):
+    name = "r1cs_n256"
+    meta = golden_json(name, "meta.json")
+    env = {"ZKHIP_FIXED_R": _le_hex(meta["r"]), "ZKHIP_FIXED_S": _le_hex(meta["s"])}
+    env.update(extra)
+    r = run(golden_path(name, "circuit.zkey"), golden_path(name, "witness.wtns"), str(tmp_path / "p.json"), str(tmp_path / "q.json"), env=env)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "p.json").read_bytes() == golden_bytes(name, "proof.json")
+    assert (tmp_path / "q.json").read_bytes() == golden_bytes(name, "public.json")
+
+
+def test_shipped_library_reads_no_probe_variable():
+    """The default build of libzkhip.so does not even contain the names of the measurement probes."""
+    blob = open(os.path.join(ROOT, "rapidsnark-old_amd", "libzkhip.so"), "rb").read()
+    for name in _RETIRED_PROBES:
+        assert name.encode() not in blob, name

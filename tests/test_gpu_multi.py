@@ -136,3 +136,30 @@ def test_shard_step_api_with_emulated_all_to_all(zk, shards):
         provers[0].prove_msm(wt.tobytes())
     for p in provers:
         p.close()
+
+
+@pytest.mark.parametrize("ranks,k", [(2, 16), (8, 14)])
+def test_bench_multi_rank_path_on_one_gpu(ranks, k):
+    """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one process per rank), with every rank on
+    cuda:0 and the collectives over gloo (ZK_BENCH_SHARE_GPU=1: the only difference to a real node is the backend of
+    all_to_all_single / all_gather): ShardedChain.submit_host_sliced, the four all_to_all rounds per proof, the 384-byte
+    all_gather, rank 0's assembly.  The run checks one sharded proof against an unsharded prover itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ZK_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
+           "--log2n", str(k), "--no-cpu"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["rccl_ranks"] == ranks and d["steps"] == 4
+    assert d["multi_gpu_proof_equals_single_gpu_proof"] is True
+    assert "chain partitioned" in d["config"]["parallelism"] and d["config"]["witness_upload"].startswith("each rank uploads 1/N")
+    assert set(d["exchange_ms"]) == {"witness_all_gather", "all_to_all_1_to_cross_inverse", "all_to_all_2_to_local",
+                                     "all_to_all_3_to_cross_forward", "all_to_all_4_to_finish"}
+    assert d["value"] > 0 and d["scaling"] == "strong"

@@ -96,6 +96,16 @@ def test_2p24_sharded8_on_one_gpu(zk):
     assert len(set(parts)) == shards
     vk = {name: np.asarray(wl[name]).tobytes() for name in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2")}
     assert zk.assemble(vk, parts, r, s) == want
+    # configs[3] AS DESIGNED (north_star: "the five MSMs and the NTT partitioned across the 8 GPUs"): the same proof through
+    # zk_multi_prover with eight shards and the chain PARTITIONED — blocks of 2^21 (local pass plan of a 2^21 block + three
+    # cross stages, k_ntt_cross<.,3>), A.w/B.w rows split by block, peer writes and cross-device events (all on device 0
+    # here), partial sums added on the host — window-precomputed tables, then tables as in the zkey
+    import bench
+    for precomp in (True, False):
+        mp = bench.MultiProverFromView(zk, wl, [0] * shards, precomp=precomp)
+        assert mp.n_shards == shards and mp.chain_partitioned
+        assert mp.prove(w, r, s) == want
+        mp.close()
     _WL.clear()
 
 

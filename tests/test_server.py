@@ -217,3 +217,127 @@ def test_queue_full_is_503(tmp_path):
     finally:
         srv.terminate()
         srv.wait(10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", ["1", "4"])
+def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch):
+    """BASELINE configs[4] on a key of its size class: no Semaphore / iden3-auth zkey exists in the image, so the key is a
+    trapdoor-VALID random R1CS with a 2^15 domain (rapidsnark_old_amd.zkgen; Semaphore is ~2^14..2^16 constraints).
+    proverServer in throughput mode — two replicas on the box's GPU, queue of 64, ZKHIP_BATCH 1 and 4 — takes 64
+    concurrent /input requests; with fixed (r, s) EVERY returned proof must be (i) the bytes the one-shot CLI writes for
+    the same files and (ii) the proof whose discrete logs follow from the toxic waste (pairing-free trapdoor check).
+    Reference shape: src/fullprover.cpp:69-101,154-159, src/main_proofserver.cpp:32-40."""
+    import concurrent.futures
+    from rapidsnark_old_amd import synth, zkgen
+    k, nreq = 15, 64
+    key = zkgen.generate(k, 2, seed=3)
+    zkgen.write_all(key, str(tmp_path))
+    os.rename(tmp_path / "circuit.zkey", tmp_path / "auth.zkey")
+    r, s = 0x0F1E2D3C4B5A6978, (1 << 231) + 4242
+    env_rs = {"ZKHIP_FIXED_R": _le_hex(r), "ZKHIP_FIXED_S": _le_hex(s)}
+    # (ii) expected proof from the toxic waste alone
+    a, b, c = zkgen.expected_proof_dlogs(key, r, s)
+    want = zk.proof_to_json(zk.g1_mul(synth.g1_gen_bytes(), a) + zk.g2_mul(synth.g2_gen_bytes(), b) + zk.g1_mul(synth.g1_gen_bytes(), c))
+    # (i) the one-shot CLI on the same files
+    cli = subprocess.run([os.path.join(ROOT, "rapidsnark-old_amd", "prover"), str(tmp_path / "auth.zkey"), str(tmp_path / "witness.wtns"),
+                          str(tmp_path / "proof.json"), str(tmp_path / "public.json")], env=dict(os.environ, **env_rs), capture_output=True, text=True, timeout=300)
+    assert cli.returncode == 0, cli.stderr
+    cli_proof, cli_public = open(tmp_path / "proof.json").read(), open(tmp_path / "public.json").read()
+    assert cli_proof == want
+    build = tmp_path / "build"
+    build.mkdir()
+    gen = build / "auth"                                    # stand-in for the circom witness generator (same argv as the reference passes)
+    gen.write_text("#!/bin/sh\ncp %s \"$2\"\n" % (tmp_path / "witness.wtns"))
+    gen.chmod(gen.stat().st_mode | stat.S_IEXEC)
+    port = _free_port()
+    env = dict(os.environ, ZKHIP_QUEUE="64", ZKHIP_WORKERS="0,0", ZKHIP_WITNESS_THREADS="4", ZKHIP_BATCH=batch, **env_rs)
+    srv = subprocess.Popen([SERVER, str(port), str(tmp_path / "auth.zkey")], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        for _ in range(1200):
+            try:
+                _http(port, "GET", "/status")
+                break
+            except (ConnectionError, urllib.error.URLError):
+                assert srv.poll() is None, srv.stderr.read().decode()
+                time.sleep(0.1)
+
+        def fire(_):
+            for _try in range(200):                          # 503 = queue full: the client retries, nothing is dropped
+                st, body, _ct = _http(port, "POST", "/input/auth", b'{"in": "1"}')
+                if st == 200:
+                    return json.loads(body)["job"]
+                assert st == 503
+                time.sleep(0.005)
+            raise AssertionError("queue never drained")
+
+        with concurrent.futures.ThreadPoolExecutor(16) as ex:
+            jobs = list(ex.map(fire, range(nreq)))
+        assert len(set(jobs)) == nreq
+        for job in jobs:
+            for _ in range(6000):
+                doc = json.loads(_http(port, "GET", "/status/%d" % job)[1])
+                if doc["status"] != "busy":
+                    break
+                time.sleep(0.005)
+            assert doc["status"] == "success", doc
+            assert doc["proof"] == cli_proof and doc["proof"] == want
+            assert doc["pubData"] == cli_public
+        assert srv.poll() is None
+    finally:
+        srv.terminate()
+        srv.wait(10)
+
+
+@pytest.mark.gpu
+def test_keep_alive_connections_and_in_process_witness(tmp_path):
+    """The front end serves several requests per connection (HTTP/1.1 keep-alive, several connections at once on its
+    worker threads), and POST /witness/:circuit takes the .wtns image itself — no generator process, no files in
+    ./build — and yields the same golden proof as the generator hand-off."""
+    import http.client
+    name = "r1cs_n64"
+    meta = golden_json(name, "meta.json")
+    srv, port = _start_server(tmp_path, [name], {"ZKHIP_FIXED_R": _le_hex(meta["r"]), "ZKHIP_FIXED_S": _le_hex(meta["s"]), "ZKHIP_QUEUE": "32",
+                                                 "ZKHIP_WORKERS": "0", "ZKHIP_HTTP_THREADS": "4"})
+    try:
+        conns = [http.client.HTTPConnection("127.0.0.1", port, timeout=30) for _ in range(3)]     # three live connections, four workers
+        wt = golden_bytes(name, "witness.wtns")
+        jobs = []
+        for i in range(12):
+            c = conns[i % 3]
+            if i % 2:
+                c.request("POST", "/witness/" + name, body=wt, headers={"Content-Type": "application/octet-stream"})
+            else:
+                c.request("POST", "/input/" + name, body=b'{"in": 1}', headers={"Content-Type": "application/json"})
+            r = c.getresponse()
+            body = r.read()
+            assert r.status == 200 and r.getheader("Connection") == "keep-alive", (r.status, body)
+            jobs.append(json.loads(body)["job"])
+        assert len(set(jobs)) == 12
+        for i, job in enumerate(jobs):
+            c = conns[i % 3]
+            for _ in range(3000):
+                c.request("GET", "/status/%d" % job)
+                doc = json.loads(c.getresponse().read())
+                if doc["status"] != "busy":
+                    break
+                time.sleep(0.005)
+            assert doc["status"] == "success", doc
+            assert doc["proof"] == golden_bytes(name, "proof.json").decode() and doc["pubData"] == golden_bytes(name, "public.json").decode()
+        # the per-job files are gone on every path; a bad image fails its own job only
+        left = [f for f in os.listdir(tmp_path / "build") if f.endswith(".wtns") or f.startswith("input_")]
+        assert left == [], left
+        c = conns[0]
+        c.request("POST", "/witness/" + name, body=b"not a wtns file")
+        bad = json.loads(c.getresponse().read())["job"]
+        c.request("GET", "/status/%d" % bad)
+        doc = json.loads(c.getresponse().read())
+        assert doc["status"] == "failed" and "Invalid file type" in doc["error"]
+        c.request("GET", "/status", headers={"Connection": "close"})
+        r = c.getresponse()
+        assert r.status == 200 and r.getheader("Connection") == "close"
+        r.read()
+        assert srv.poll() is None
+    finally:
+        srv.terminate()
+        srv.wait(10)
