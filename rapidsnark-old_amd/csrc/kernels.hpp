@@ -46,6 +46,25 @@ struct NttTables {
     const Fr *coset;     // n^-1 * w_2n^brev(p) for position p < n  (bit-reversed order; canonical words of the 2^261 form)
     const Fr *ninv;      // single element n^-1 (Montgomery)
 };
+// ---------------------------------------------------------------- nttpair.hip
+// The coset-evaluation pipeline of the proof path (ifft, coset shift, fft of a|b|c: src/groth16.cpp:98-155) with radix-8
+// register butterflies; tables for ONE local transform size (the whole domain, or one block of a partitioned chain).
+struct NttPair {
+    uint32_t L = 0, Lg = 0, m = 0;        // local bits (0 = not built), domain bits, tile bits
+    uint32_t ngroups = 0, g[2] = {0, 0};  // strided bits: none, one pass, or two
+    TwEntry *rfwd = nullptr, *rinv = nullptr;
+    Fr *tinv = nullptr, *tfwd = nullptr, *dtab = nullptr, *t2inv = nullptr, *t2fwd = nullptr;
+    NttPair() {}
+    NttPair(const NttPair &) = delete;
+    NttPair &operator=(const NttPair &) = delete;
+    ~NttPair() { release(); }
+    void build(uint32_t logn_global, uint32_t logn_local, uint32_t block_index, hipStream_t s);
+    void release();
+};
+bool ntt_pair_supported(uint32_t local_logn);
+// in place on `batch` vectors of 2^L elements, `stride_elems` apart: natural order in, natural order out
+void launch_ntt_coset_pair(Fr *data, uint64_t stride_elems, uint32_t batch, const NttPair &t, hipStream_t s);
+
 // fill the tables (device memory already allocated: n/2, n/2, n, 1 elements)
 void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s);
 // Batched in-place transforms of `batch` polynomials laid out at data + k*stride_elems.

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_build_tables(TwEntry *fwd, TwEntry *inv
             }
         }
         uint32_t k = brev((uint32_t)i, logn);
-        store_el(coset + i, Fr29::store(Fr29::from_mont256(Fr::mul(fr_pow(s_w2n, k), s_ninv))));
+        if (coset) store_el(coset + i, Fr29::store(Fr29::from_mont256(Fr::mul(fr_pow(s_w2n, k), s_ninv))));
         if (i == 0) store_el(ninv_out, Fr29::store(Fr29::from_mont256(s_ninv)));
     }
 }

@@ -193,6 +193,7 @@ struct zk_prover {
     DevBuf<Fr> csr_val;
     DevBuf<TwEntry> tw_fwd, tw_inv;
     DevBuf<Fr> tw_coset, tw_ninv;
+    NttPair pair;               // nttpair.hip: tables of the coset-evaluation pipeline for this prover's block (pair.L == 0: not used)
     Slice sv, sh;              // this shard's slice of witness indices / domain indices
     uint32_t c_idx_min = 0;    // C-MSM: local witness index >= c_idx_min maps to pointsC[idx - c_idx_min]
     bool precomp = false;      // window-precomputed tables (ZK_FLAG_PRECOMP): tables hold W rows of n points
@@ -571,12 +572,21 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         clk.lap("CSR build (device)", s);
     }
 
-    // --- twiddles
-    p->tw_fwd.alloc(n > 1 ? n / 2 : 1);
-    p->tw_inv.alloc(n > 1 ? n / 2 : 1);
-    p->tw_coset.alloc(n);
-    p->tw_ninv.alloc(1);
-    launch_ntt_build_tables(p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p, p->logn, s);
+    // --- twiddles.  The proof path runs the register-butterfly pipeline of nttpair.hip on this prover's block (its own
+    // tables); the radix-2 tables of ntt.hip are only needed by the cross-GPU stages of a partitioned chain (full-size
+    // twiddles) and where the pipeline does not apply (blocks of fewer than 8 elements)
+    {
+        const uint32_t local_logn = p->logn - p->log_shards_chain();
+        const bool pair = ntt_pair_supported(local_logn) && !probe_env("ZKHIP_NTT_RADIX2");
+        if (pair) p->pair.build(p->logn, local_logn, p->part ? p->shard_index : 0u, s);
+        if (!pair || p->part) {
+            p->tw_fwd.alloc(n > 1 ? n / 2 : 1);
+            p->tw_inv.alloc(n > 1 ? n / 2 : 1);
+            if (!pair) p->tw_coset.alloc(n);
+            p->tw_ninv.alloc(1);
+            launch_ntt_build_tables(p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p, p->logn, s);
+        }
+    }
     clk.lap("twiddle tables", s);
 
     // --- point tables: this shard's contiguous slices
@@ -937,8 +947,12 @@ void phase_local(zk_prover *p) {
     NttTables tb = c.tables();
     const bool a2a = p->part && !p->have_peers;          // blocks travel through the caller's all_to_all
     if (a2a) launch_chunk_unpack(c.abc, p->pk_use, 3, p->logn, p->log_shards, c.s);
-    launch_ntt_dif_inverse(c.abc, nl, 3 * c.q.count, tb, c.s, local_logn);
-    launch_ntt_dit_forward(c.abc, nl, 3 * c.q.count, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
+    if (p->pair.L) {
+        launch_ntt_coset_pair(c.abc, nl, 3 * c.q.count, p->pair, c.s);      // inverse, coset shift * 1/n, forward: nttpair.hip
+    } else {
+        launch_ntt_dif_inverse(c.abc, nl, 3 * c.q.count, tb, c.s, local_logn);
+        launch_ntt_dit_forward(c.abc, nl, 3 * c.q.count, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
+    }
     if (a2a) launch_chunk_pack(p->pk_use, c.abc, 3, p->logn, p->log_shards, c.s);
     p->phase_next = p->part ? 3 : 4;
 }
@@ -1771,8 +1785,15 @@ int zk_fr_abc_to_h(uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n) {
         HIP_TRY(hipMemcpy(abc.p + n, b, n * 32, hipMemcpyHostToDevice));
         launch_fr_mul_vec(abc.p + 2 * n, abc.p, abc.p + n, n, 0);      // c = a o b in the reference's form
         launch_fr_to_internal(abc.p, 3 * n, 1, 0);
-        launch_ntt_dif_inverse(abc.p, n, 3, tb.t, 0);
-        launch_ntt_dit_forward(abc.p, n, 3, tb.t, 0, tb.coset.p);
+        if (ntt_pair_supported(logn) && !probe_env("ZKHIP_NTT_RADIX2")) {      // the proof path's pipeline (nttpair.hip)
+            NttPair pr;
+            pr.build(logn, logn, 0, 0);
+            launch_ntt_coset_pair(abc.p, n, 3, pr, 0);
+            HIP_TRY(hipStreamSynchronize(0));
+        } else {
+            launch_ntt_dif_inverse(abc.p, n, 3, tb.t, 0);
+            launch_ntt_dit_forward(abc.p, n, 3, tb.t, 0, tb.coset.p);
+        }
         launch_abc_to_h(hh.p, abc.p, abc.p + n, abc.p + 2 * n, n, 0);
         HIP_TRY(hipMemcpy(h, hh.p, n * 32, hipMemcpyDeviceToHost));
     });

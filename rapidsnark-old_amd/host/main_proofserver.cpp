@@ -10,9 +10,9 @@
 // (a .wtns image as the body) instead of running the generator; everything else is unchanged.
 // The reference runs ONE HTTP thread (Http::Endpoint::options().threads(1), main_proofserver.cpp:34) and one request
 // per connection; behind eight GPUs that loop is the bound (round-2 measurement: 2018 proofs/s through REST against
-// 3300 through the C-ABI at 2^14).  Here ZKHIP_HTTP_THREADS workers (default 8) all accept on the listening socket
-// and serve their connection with keep-alive (requests back to back until the client closes or is idle for 5 s), so
-// parsing a body, answering status polls and enqueueing jobs happen on different cores.  Bodies up to 128000000
+// 3300 through the C-ABI at 2^14).  Here ZKHIP_HTTP_THREADS workers (default 8) each poll the listening socket and
+// the connections they accepted, with keep-alive (any number of persistent connections; idle ones are dropped after
+// 30 s), so parsing a body, answering status polls and enqueueing jobs happen on different cores.  Bodies up to 128000000
 // bytes (main_proofserver.cpp:32).
 #include <arpa/inet.h>
 #include <cerrno>
@@ -21,7 +21,10 @@
 #include <iostream>
 #include <netinet/in.h>
 #include <string>
+#include <fcntl.h>
 #include <netinet/tcp.h>
+#include <poll.h>
+#include <ctime>
 #include <sys/socket.h>
 #include <sys/time.h>
 #include <thread>
@@ -36,10 +39,19 @@ static bool send_all(int fd, const std::string &s) {
     size_t off = 0;
     while (off < s.size()) {
         ssize_t k = ::send(fd, s.data() + off, s.size() - off, MSG_NOSIGNAL);
+        if (k < 0 && errno == EINTR) continue;
         if (k <= 0) return false;
         off += (size_t)k;
     }
     return true;
+}
+// recv that is not fooled by a signal landing on this thread (the GPU runtime's threads share the process)
+static ssize_t recv_some(int fd, char *buf, size_t len) {
+    for (;;) {
+        ssize_t k = ::recv(fd, buf, len, 0);
+        if (k < 0 && errno == EINTR) continue;
+        return k;
+    }
 }
 
 // per connection: does the client want it kept open after this response?
@@ -65,7 +77,7 @@ static void handle(int fd, FullProver &fp, std::string &buf) {
     size_t hdr_end = buf.find("\r\n\r\n");
     char tmp[65536];
     while (hdr_end == std::string::npos) {
-        ssize_t k = ::recv(fd, tmp, sizeof tmp, 0);
+        ssize_t k = recv_some(fd, tmp, sizeof tmp);
         if (k <= 0) return;                      // closed, or idle for longer than the receive timeout
         buf.append(tmp, (size_t)k);
         hdr_end = buf.find("\r\n\r\n");
@@ -103,7 +115,7 @@ static void handle(int fd, FullProver &fp, std::string &buf) {
     std::string body = buf.substr(hdr_end + 4);
     if (expect100 && body.size() < clen) send_all(fd, "HTTP/1.1 100 Continue\r\n\r\n");
     while (body.size() < clen) {
-        ssize_t k = ::recv(fd, tmp, sizeof tmp, 0);
+        ssize_t k = recv_some(fd, tmp, sizeof tmp);
         if (k <= 0) return;
         body.append(tmp, (size_t)k);
     }
@@ -170,23 +182,65 @@ int main(int argc, char **argv) {
         if (nthreads < 1) nthreads = 1;
         if (nthreads > 256) nthreads = 256;
         std::cerr << "Server ready on port " << port << "...\n";
+        // Every worker polls the listening socket and the connections IT accepted: a kept-alive connection that is silent
+        // costs a poll slot, not a thread (16 persistent clients on 8 workers used to wait for each other's idle timeouts).
+        {
+            int fl = fcntl(ls, F_GETFL, 0);
+            fcntl(ls, F_SETFL, fl | O_NONBLOCK);          // a connection another worker took first: EAGAIN, not a blocked thread
+        }
         auto worker = [&] {
+            struct Conn {
+                int fd;
+                std::string carry;
+                time_t last;
+            };
+            std::vector<Conn> conns;
+            std::vector<pollfd> pfds;
             for (;;) {
-                int fd = ::accept(ls, nullptr, nullptr);
-                if (fd < 0) {
-                    if (errno == EINTR || errno == ECONNABORTED) continue;
-                    std::cerr << "accept: " << strerror(errno) << '\n';
+                pfds.clear();
+                pfds.push_back(pollfd{ls, POLLIN, 0});
+                for (auto &c : conns) pfds.push_back(pollfd{c.fd, POLLIN, 0});
+                const int pr = ::poll(pfds.data(), (nfds_t)pfds.size(), conns.empty() ? -1 : 1000);
+                if (pr < 0 && errno != EINTR) {
+                    std::cerr << "poll: " << strerror(errno) << '\n';
                     return;
                 }
-                int on = 1;
-                setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &on, sizeof on);
-                timeval idle{5, 0};              // a kept-alive connection that stays silent gives its worker back
-                setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &idle, sizeof idle);
-                std::string carry;
-                do {
-                    handle(fd, fullProver, carry);
-                } while (t_keep);
-                ::close(fd);
+                const time_t now = time(nullptr);
+                // serve what is readable (one request per turn and connection; requests already buffered follow at once)
+                for (size_t i = 0; i < conns.size();) {
+                    Conn &c = conns[i];
+                    const bool readable = pr > 0 && (pfds[i + 1].revents & (POLLIN | POLLHUP | POLLERR));
+                    bool keep = true;
+                    if (readable || !c.carry.empty()) {
+                        do {
+                            handle(c.fd, fullProver, c.carry);
+                            keep = t_keep;
+                        } while (keep && c.carry.find("\r\n\r\n") != std::string::npos);
+                        c.last = now;
+                    } else if (now - c.last > 30) {
+                        keep = false;                     // idle for half a minute
+                    }
+                    if (!keep) {
+                        ::close(c.fd);
+                        conns[i] = std::move(conns.back());
+                        conns.pop_back();
+                        if (i + 1 < pfds.size()) pfds[i + 1] = pfds.back();
+                        pfds.pop_back();
+                    } else {
+                        i++;
+                    }
+                }
+                if (pr > 0 && (pfds[0].revents & POLLIN)) {
+                    for (int burst = 0; burst < 16; burst++) {
+                        int fd = ::accept(ls, nullptr, nullptr);
+                        if (fd < 0) break;               // EAGAIN: somebody else has it (or nothing left)
+                        int on = 1;
+                        setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &on, sizeof on);
+                        timeval slow{5, 0};              // bounds a client that stops in the middle of a request
+                        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &slow, sizeof slow);
+                        conns.push_back(Conn{fd, std::string(), now});
+                    }
+                }
             }
         };
         std::vector<std::thread> pool;

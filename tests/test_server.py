@@ -284,6 +284,14 @@ def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch):
             assert doc["proof"] == cli_proof and doc["proof"] == want
             assert doc["pubData"] == cli_public
         assert srv.poll() is None
+    except Exception:
+        srv.terminate()
+        try:
+            err = srv.communicate(timeout=10)[1].decode(errors="replace")
+        except Exception:                                   # noqa: BLE001
+            err = "(no stderr)"
+        print("proverServer exit code %s, stderr tail:\n%s" % (srv.returncode, err[-3000:]))
+        raise
     finally:
         srv.terminate()
         srv.wait(10)

@@ -79,7 +79,7 @@ def main():
     le = lambda x: int(x).to_bytes(32, "little").hex()
     env = dict(os.environ, ZKHIP_QUEUE=str(nreq + 8), ZKHIP_WORKERS=workers, ZKHIP_WITNESS_THREADS="8", ZKHIP_FIXED_R=le(r), ZKHIP_FIXED_S=le(s_))
     srv = subprocess.Popen([os.path.join(ROOT, "rapidsnark-old_amd", "proverServer"), str(port), os.path.join(d, "auth.zkey")], cwd=d, env=env,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                           stdout=subprocess.DEVNULL, stderr=open(os.environ["SERVER_LOG"], "w") if os.environ.get("SERVER_LOG") else subprocess.DEVNULL)
     try:
         for _ in range(600):
             try:
@@ -108,6 +108,8 @@ def main():
         print(json.dumps({"log2n": k, "requests": nreq, "workers": workers, "route": post, "succeeded": ok, "proofs_equal_to_the_trapdoor_prediction": verified, "seconds": round(dt, 3),
                           "proofs_per_s": round(nreq / dt, 1), "ms_per_proof": round(dt / nreq * 1e3, 2)}))
     finally:
+        if srv.poll() is not None:
+            print("SERVER DIED with code", srv.returncode)
         srv.terminate(); srv.wait(10)
 
 
