@@ -452,7 +452,18 @@ struct Fp29 {
         return t;    // limbs 0..7 in [0, 2^29)
     }
     // exact: value == 0 (mod p).  After reduce_near_zero the value is in (-p, p): zero iff all limbs are.
+    // Four-instruction filter in front of it: value = k*p needs l[0] = k*p[0] (mod 2^29) — the lowest limb takes no carry
+    // from anywhere, lazy or not — i.e. l[0] * p[0]^-1 = k, a SMALL number (|k| <= 32 for values in (-32p, 32p)).  A
+    // non-zero value passes with probability 65 / 2^29; the exact test behind it then runs for (almost) no lane.
+    ZK_HD bool may_be_zero() const {
+        const uint32_t k = (uint32_t)l[0] * ((0u - N0INV) & (uint32_t)MASK);       // p[0]^-1 = -N0INV (mod 2^29)
+        return ((k + 32u) & (uint32_t)MASK) < 65u;
+    }
+#if defined(ZK_NO_ZERO_FILTER)
     ZK_HD bool is_zero() const { return reduce_near_zero(*this).is_zero_raw(); }
+#else
+    ZK_HD bool is_zero() const { return may_be_zero() && reduce_near_zero(*this).is_zero_raw(); }
+#endif
 
     // canonical representative in [0, p), limbs 0..8 all non-negative
     ZK_HD static Fq29 canonical(const Fq29 &a) {
