@@ -133,7 +133,9 @@ __device__ __forceinline__ void exchange(int32_t *lds, Fr29 (&x)[8], uint32_t T,
 // bottom of the processed range and the window (uniform) e mod 2^level depends on c only: the twiddles are wave-uniform
 // constants (1, w_4, w_8^k), and the butterflies whose twiddle is 1 skip the multiplication.
 // Butterflies are multiplied in PAIRS (field29.hpp run2), one pair after the other (few values live at a time).
-// (Measured and dropped: loading a stage's four twiddles one stage ahead — 36 more live registers, 4 % more instructions,
+// (Measured and dropped: three waves per SIMD — 168 VGPRs, 44-256 B of scratch, the limb planes exchanged in two rounds
+// through 40 KiB of LDS: mid pass 1.68 -> 1.65 ms, forward outer pass 0.91 -> 1.08 ms, pipelined proof unchanged; and
+// loading a stage's four twiddles one stage ahead — 36 more live registers, 4 % more instructions,
 // mid pass 1.64 -> 1.81 ms: the kernels are bound by VALU issue at ~4.7 cycles per instruction like the bucket kernels,
 // not by the L2 trips of the twiddle loads.)
 // Bounds (field29.hpp): DIF keeps every value carried ("tight": a difference of two tight values is a valid factor);

@@ -112,3 +112,39 @@ def test_abc_to_h_matches_oracle(zk, n):
     want = [(x * y - z) % bn.R_MOD for x, y, z in zip(ae, be, ce)]
     got = unpack(zk.fr_abc_to_h(pack(bn.to_mont(v, bn.R_MOD) for v in a), pack(bn.to_mont(v, bn.R_MOD) for v in b)))
     assert got == want
+
+
+@pytest.mark.parametrize("logn", [3, 5, 9, 10, 11, 12, 13, 14, 16, 19, 21, 22, 23])
+def test_abc_to_h_against_the_c_restatement_at_every_pass_plan(zk, logn):
+    """The coset-evaluation pipeline (csrc/nttpair.hip) at every shape of its pass plan — a single tile (<= 2^11), tile + one
+    strided pass of 1..10 bits (256 threads), of 11 bits (512 threads, 2^22), two strided passes (2^23) — against the C
+    restatement's bit-reversal FFT (oracle/c/zk_oracle.c, src/groth16.cpp:98-163): c = a o b, three times ifft / coset shift
+    / fft, h = fromMontgomery(a.b - c).  Compared on all positions up to 2^14 and on 4096 sampled ones above."""
+    import numpy as np
+    from oracle import c_oracle as co
+    n = 1 << logn
+    rng = np.random.default_rng(77 + logn)
+    from rapidsnark_old_amd import synth
+    a = synth.random_fr_bytes(rng, n).reshape(-1)                  # Montgomery form, like the reference's a[] / b[]
+    b = synth.random_fr_bytes(rng, n).reshape(-1)
+    c = np.frombuffer(co.fr_mul_vec(a, b), dtype=np.uint8)
+    # powers of w_2n in Montgomery form, by doubling (vector products of the restatement)
+    w2n = bn.to_mont(bn.fr_root(logn + 1), bn.R_MOD)
+    pw = np.frombuffer(le(bn.to_mont(1, bn.R_MOD)), dtype=np.uint8).copy()
+    step = w2n
+    while pw.size < n * 32:
+        pw = np.concatenate([pw, np.frombuffer(co.fr_mul_vec(pw, np.tile(np.frombuffer(le(step), dtype=np.uint8), pw.size // 32)), dtype=np.uint8)])
+        step = bn.mont_mul(step, step, bn.R_MOD)
+
+    def coset(v):
+        return np.frombuffer(co.fr_fft(co.fr_mul_vec(co.fr_fft(v, inverse=True), pw), inverse=False), dtype=np.uint8)
+
+    ae, be, ce = coset(a), coset(b), coset(c)
+    ab = np.frombuffer(co.fr_mul_vec(ae, be), dtype=np.uint8)
+    got = np.frombuffer(zk.fr_abc_to_h(a, b), dtype=np.uint8)
+    idx = range(n) if logn <= 14 else sorted(set(int(i) for i in rng.integers(0, n, 4096)) | {0, 1, n - 1, n // 2, 2047, 2048})
+    rinv = pow(bn.MONT_R, -1, bn.R_MOD)
+    for i in idx:
+        x = int.from_bytes(ab[32 * i:32 * i + 32].tobytes(), "little")
+        z = int.from_bytes(ce[32 * i:32 * i + 32].tobytes(), "little")
+        assert int.from_bytes(got[32 * i:32 * i + 32].tobytes(), "little") == (x - z) * rinv % bn.R_MOD, (logn, i)
