@@ -261,6 +261,7 @@ __device__ __forceinline__ void run_plan(Fr29 (&x)[8], int32_t *lds, uint32_t T,
 
 struct PairDev {
     uint32_t m;                  // tile bits
+    uint32_t batch, tiles;       // vectors per launch, workgroups per vector
     uint64_t nloc;               // elements per vector
     const TwEntry *rfwd, *rinv;  // w_4096^k, w_4096^-k, k < 2048
     const Fr *tinv, *tfwd;       // per-element tables (nullptr when the transform is a single tile)
@@ -272,9 +273,21 @@ struct PairDev {
 __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_elems, PairDev t) {
     extern __shared__ int32_t lds[];
     typedef Fr29 F;
-    Fr *xg = data + (uint64_t)blockIdx.y * stride_elems;
+    // The vectors (a, b, c) of a tile run next to each other ON THE SAME XCD (workgroup i goes to XCD i mod 8, each XCD has
+    // its own L2): the per-element tables Tinv' / T of the tile are fetched from HBM once and found in L2 by the other two.
+    // id = (g, x) with x = id mod 8: tile = 8 * (g / batch) + x, vector = g mod batch (tile counts that are multiples of 8).
+    uint32_t vec, tile;
+    if ((t.tiles & 7u) == 0) {
+        const uint32_t g = blockIdx.x >> 3, x = blockIdx.x & 7u;
+        vec = g % t.batch;
+        tile = ((g / t.batch) << 3) | x;
+    } else {
+        vec = blockIdx.x % t.batch;
+        tile = blockIdx.x / t.batch;
+    }
+    Fr *xg = data + (uint64_t)vec * stride_elems;
     const uint32_t T = threadIdx.x;
-    const uint64_t wg_base = (uint64_t)blockIdx.x << 11;
+    const uint64_t wg_base = (uint64_t)tile << 11;
     const uint32_t wtop = t.plan.wlo[t.plan.nph - 1];            // DIF starts (and DIT ends) in the top window: coalesced
     F x[8];
     const bool active = wg_base + v_of(T, 0, wtop) < t.nloc;     // nloc < 2^11: the tail of the only workgroup idles (but meets the barriers)
@@ -538,6 +551,7 @@ void launch_ntt_coset_pair(Fr *data, uint64_t stride, uint32_t batch, const NttP
         PairDev d;
         memset(&d, 0, sizeof d);
         d.m = tb.m;
+        d.batch = batch;
         d.nloc = 1ull << tb.L;
         d.rfwd = tb.rfwd;
         d.rinv = tb.rinv;
@@ -546,8 +560,9 @@ void launch_ntt_coset_pair(Fr *data, uint64_t stride, uint32_t batch, const NttP
         d.dtab = tb.dtab;
         d.plan = plan_windows(0, tb.m, 11);
         const uint32_t wgs = (uint32_t)(((1ull << tb.L) + 2047) >> 11);
+        d.tiles = wgs;
         const size_t shmem = (size_t)9 * 2048 * 4;
-        hipLaunchKernelGGL(k_ntt_mid, dim3(wgs, batch), dim3(256), shmem, s, data, stride, d);
+        hipLaunchKernelGGL(k_ntt_mid, dim3(wgs * batch), dim3(256), shmem, s, data, stride, d);
         ZK_LAUNCH_OK("ntt middle pass");
     }
     if (tb.ngroups == 2) {

@@ -149,11 +149,27 @@ def test_bench_multi_rank_path_on_one_gpu(ranks, k):
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, ZK_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
-           "--log2n", str(k), "--no-cpu"]
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    import gc
+    import socket
+    gc.collect()                       # provers of earlier tests still hold streams (hardware queues) of the one GPU the ranks share
+    # the ranks share ONE GPU with this pytest process: few hardware queues each, or the driver time-slices them (the command
+    # alone takes 4-8 s; 15 of 15 stand-alone runs passed, one run inside a long pytest session once sat in its time-out)
+    env = dict(os.environ, ZK_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", GPU_MAX_HW_QUEUES="2")
+    res = None
+    for attempt in range(2):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
+               "--log2n", str(k), "--no-cpu"]
+        try:
+            res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+            break
+        except subprocess.TimeoutExpired:
+            if attempt:
+                raise
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
     d = json.loads(lines[0])

@@ -15,7 +15,7 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         agg[key] += float(r['Counter_Value']); cnt[key] += 1
 if nproofs <= 0:
     nproofs = float(max(1, cnt.get('k_spmv_abc', 1)))
-skip = ('precomp', 'chain', 'build_tables', 'fq_to_internal', 'fr_convert', 'csr', 'fixed_base')
+skip = ('precomp', 'chain', 'build_tables', 'pair_tables', 'fq_to_internal', 'fr_convert', 'csr', 'fixed_base')
 rows = [(v / nproofs, k, cnt[k] / nproofs) for k, v in agg.items() if not any(x in k for x in skip)]
 tot = sum(v for v, _, _ in rows)
 for v, k, c in sorted(rows, reverse=True)[:18]:
