@@ -242,6 +242,35 @@ struct CrossOut {
     Fr *base[8];          // where the result for block s goes (peer memory or xb itself)
 };
 
+// stage T of the LG cross stages on the G = 2^LG values of one block offset (template recursion: the optimiser would not
+// unroll the stage loop of the radix-8 case, which put the eight values into scratch memory)
+template <bool DIF, int LG, int T>
+__device__ __forceinline__ void cross_stage(Fr29 (&x)[1 << LG], const TwEntry *tw, uint32_t logn, uint64_t o, uint64_t block) {
+    constexpr int G = 1 << LG;
+    // DIF: bit b = logn-1-T, partner differs in block bit LG-1-T; DIT: b = logn-LG+T, block bit T
+    constexpr int kb = DIF ? LG - 1 - T : T;
+    const uint32_t b = DIF ? logn - 1 - T : logn - LG + T;
+    const uint32_t tshift = logn - 1 - b;
+#pragma unroll
+    for (int pi = 0; pi < G / 2; pi++) {          // the G/2 butterflies of the stage: pi with a zero inserted at bit kb
+        const int sidx = ((pi >> kb) << (kb + 1)) | (pi & ((1 << kb) - 1));
+        const int s1 = sidx | (1 << kb);
+        // j = low b bits of the global index s*block + o
+        const uint64_t j = (uint64_t)(sidx & ((1 << kb) - 1)) * block + o;
+        const Fr29 w = load_tw(tw + (j << tshift));
+        Fr29 u = x[sidx], v = x[s1];
+        if (DIF) {
+            x[sidx] = Fr29::add(u, v);
+            x[s1] = Fr29::mul(Fr29::sub(u, v), w);
+        } else {
+            v = Fr29::mul(v, w);
+            x[sidx] = Fr29::add(u, v);
+            x[s1] = Fr29::sub(u, v);
+        }
+    }
+    if constexpr (T + 1 < LG) cross_stage<DIF, LG, T + 1>(x, tw, logn, o, block);
+}
+
 template <bool DIF, int LG>
 __global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, uint64_t in_src_stride, uint64_t in_poly_stride, CrossOut out,
                                                    uint64_t out_poly_stride, uint64_t out_offset,
@@ -255,30 +284,7 @@ __global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, uint64_t in_src
     Fr29 x[G];
 #pragma unroll
     for (int sidx = 0; sidx < G; sidx++) x[sidx] = Fr29::load(load_el(src + (uint64_t)sidx * in_src_stride));
-#pragma unroll
-    for (int t = 0; t < LG; t++) {
-        // DIF: bit b = logn-1-t, partner differs in block bit LG-1-t; DIT: b = logn-LG+t, block bit t
-        const int kb = DIF ? LG - 1 - t : t;
-        const uint32_t b = DIF ? logn - 1 - t : logn - LG + t;
-        const uint32_t tshift = logn - 1 - b;
-#pragma unroll
-        for (int sidx = 0; sidx < G; sidx++) {
-            if (sidx & (1 << kb)) continue;
-            const int s1 = sidx | (1 << kb);
-            // j = low b bits of the global index s*block + o
-            const uint64_t j = (uint64_t)(sidx & ((1 << kb) - 1)) * block + o;
-            const Fr29 w = load_tw(tw + (j << tshift));
-            Fr29 u = x[sidx], v = x[s1];
-            if (DIF) {
-                x[sidx] = Fr29::add(u, v);
-                x[s1] = Fr29::mul(Fr29::sub(u, v), w);
-            } else {
-                v = Fr29::mul(v, w);
-                x[sidx] = Fr29::add(u, v);
-                x[s1] = Fr29::sub(u, v);
-            }
-        }
-    }
+    cross_stage<DIF, LG, 0>(x, tw, logn, o, block);
 #pragma unroll
     for (int sidx = 0; sidx < G; sidx++)
         store_el(out.base[sidx] + (uint64_t)poly * out_poly_stride + out_offset + op, Fr29::store(x[sidx]));
