@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1 (default, single GPU): consecutive proofs overlap through zk_prove_dev_submit / zk_prove_collect "
                          "(two in flight); 0: strictly one proof at a time (zk_prove_dev)")
-    ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = by size: 3 with host witnesses / 2 with resident ones from 2^19 up, 8 below; max 8)")
+    ap.add_argument("--in-flight", type=int, default=0, help="proofs in flight per GPU (0 = by size: 8 below 2^19, 6 up to 2^22, above 3 with host witnesses / 2 with resident ones; max 8)")
     ap.add_argument("--batch", type=int, default=0, help="N = 1, host witnesses: B >= 2 = B witnesses per submission (zk_prove_batch_submit; small circuits). --steps must be a multiple of B")
     ap.add_argument("--collector-thread", type=int, default=1, help="N = 1: collect on a second host thread (1, default) or in the submitting thread (0)")
     ap.add_argument("--witness-in", choices=["host", "hbm"], default="host",
@@ -442,7 +442,8 @@ def default_depth(k, in_hbm, world=1):
     if k < 19:
         return 8
     if k <= 22 and world == 1:          # four lanes of streams per prover up to 2^22 (csrc/prover.hip): 2^20 11.1 -> 10.2 ms with six in
-        return 6 if k <= 20 else 4          # flight; 2^22 with four: the host-witness rate reaches the resident one (36.6 -> 35.6 ms)
+        return 6                            # flight; 2^22: four / five / six in flight 33.5 / 32.6 / 32.5 ms with host witnesses (r03 A/B, three
+                                            # alternations), resident unchanged at 32.5: the deeper pipeline hides the 128 MiB upload completely
     return 2 if in_hbm else 3
 
 

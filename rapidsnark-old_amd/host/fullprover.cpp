@@ -429,7 +429,7 @@ void FullProver::deviceLoop(size_t worker) {
         // depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs GiBs of
         // workspace); small circuits are latency-bound per proof and want the maximum
         const uint32_t ds = circuits[job->circuit].header->domainSize;
-        const size_t depth = ds > (1u << 22) ? 3 : (ds > (1u << 20) ? 4 : (ds >= (1u << 19) ? 6 : ZK_MAX_IN_FLIGHT));
+        const size_t depth = ds > (1u << 22) ? 3 : (ds >= (1u << 19) ? 6 : ZK_MAX_IN_FLIGHT);
         {
             std::unique_lock<std::mutex> lk(wm);
             cv.wait(lk, [&] { return perCircuit[job->circuit] < depth; });
