@@ -239,7 +239,8 @@ void FullProver::abort() {
             }
             q->clear();
         }
-        return;                  // (a job inside its generator right now finishes it and is dropped in witnessLoop)
+        abortEpoch++;            // a job inside its generator right now finishes it and is dropped in witnessLoop
+        return;
     }
     if (status == busy && executing) executing->canceled = true;
 }
@@ -276,6 +277,7 @@ bool FullProver::enqueue(std::string input, std::string circuit, uint64_t &id) {
     if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
     JobPtr j = std::make_shared<Job>();
     j->id = id = nextId++;
+    j->epoch = abortEpoch;
     j->input = std::move(input);
     j->circuit = std::move(circuit);
     incoming.push_back(j);
@@ -300,6 +302,7 @@ bool FullProver::enqueueWitness(std::string wtnsImage, std::string circuit, uint
     std::lock_guard<std::mutex> guard(mtx);
     if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
     j->id = id = nextId++;
+    j->epoch = abortEpoch;
     remember(j);
     if (!error.empty()) {
         j->wtns.reset();
@@ -344,7 +347,7 @@ void FullProver::witnessLoop() {
         }
         std::lock_guard<std::mutex> guard(mtx);
         inWitness--;
-        if (job->canceled) {             // /cancel arrived while the generator ran
+        if (job->canceled || job->epoch < abortEpoch) {             // /cancel arrived while the generator ran
             job->wtns.reset();
             job->status = aborted;
             continue;

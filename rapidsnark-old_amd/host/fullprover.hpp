@@ -63,6 +63,7 @@ private:
         const uint8_t *wtnsData = nullptr;
         bool canceled = false;
         bool haveImage = false;                        // `input` holds a .wtns image, not circom input JSON
+        uint64_t epoch = 0;                            // value of abortEpoch when the job was accepted
     };
     typedef std::shared_ptr<Job> JobPtr;
 
@@ -81,6 +82,7 @@ private:
     // throughput mode
     std::deque<JobPtr> incoming, readyJobs;
     size_t inWitness = 0;                      // jobs inside a witness generator right now (count against queueCap)
+    uint64_t abortEpoch = 0;                   // POST /cancel: jobs accepted before it that have not reached a GPU are dropped
     std::map<uint64_t, JobPtr> jobs;           // recent jobs by id (bounded)
     std::vector<std::thread> threads;
 

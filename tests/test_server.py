@@ -349,3 +349,55 @@ def test_keep_alive_connections_and_in_process_witness(tmp_path):
     finally:
         srv.terminate()
         srv.wait(10)
+
+
+@pytest.mark.gpu
+def test_cancel_in_throughput_mode_drops_what_has_not_reached_a_gpu(tmp_path):
+    """POST /cancel with a queue (src/fullprover.cpp:206-214 aborts the one running proof; with a queue it drops every job
+    that has not reached a GPU: waiting for a witness generator, inside one, or ready for a dispatcher).  The server goes on
+    serving afterwards."""
+    name = "r1cs_n64"
+    meta = golden_json(name, "meta.json")
+    build = tmp_path / "build"
+    build.mkdir()
+    z = tmp_path / (name + ".zkey")
+    shutil.copy(golden_path(name, "circuit.zkey"), z)
+    gen = build / name
+    gen.write_text("#!/bin/sh\nsleep 0.4\ncp %s \"$2\"\n" % golden_path(name, "witness.wtns"))      # a slow generator
+    gen.chmod(gen.stat().st_mode | stat.S_IEXEC)
+    port = _free_port()
+    env = dict(os.environ, ZKHIP_FIXED_R=_le_hex(meta["r"]), ZKHIP_FIXED_S=_le_hex(meta["s"]), ZKHIP_QUEUE="16", ZKHIP_WORKERS="0",
+               ZKHIP_WITNESS_THREADS="1")
+    srv = subprocess.Popen([SERVER, str(port), str(z)], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):
+            try:
+                _http(port, "GET", "/status")
+                break
+            except (ConnectionError, urllib.error.URLError):
+                assert srv.poll() is None, srv.stderr.read().decode()
+                time.sleep(0.1)
+        jobs = [json.loads(_http(port, "POST", "/input/" + name, b"{}")[1])["job"] for _ in range(5)]
+        time.sleep(0.1)                                   # job 1 is inside the generator, 2..5 wait for it
+        assert _http(port, "POST", "/cancel")[0] == 200
+        docs = {}
+        for job in jobs:
+            for _ in range(400):
+                docs[job] = json.loads(_http(port, "GET", "/status/%d" % job)[1])
+                if docs[job]["status"] != "busy":
+                    break
+                time.sleep(0.01)
+        assert [docs[j]["status"] for j in jobs] == ["aborted"] * 5, docs
+        after = json.loads(_http(port, "POST", "/input/" + name, b"{}")[1])["job"]
+        for _ in range(600):
+            doc = json.loads(_http(port, "GET", "/status/%d" % after)[1])
+            if doc["status"] != "busy":
+                break
+            time.sleep(0.01)
+        assert doc["status"] == "success" and doc["proof"] == golden_bytes(name, "proof.json").decode()
+        left = [f for f in os.listdir(build) if f.endswith(".wtns") or f.startswith("input_")]
+        assert left == [], left
+        assert srv.poll() is None
+    finally:
+        srv.terminate()
+        srv.wait(10)
