@@ -477,8 +477,8 @@ def plan_window_bits(n, world, precomp):
     per = (n + world - 1) // world
     lg = per.bit_length() - 1
     if precomp:
-        c = max(2, lg - 2)
-        return min(20, 18 if c == 17 else c)
+        c = 19 if lg == 20 else max(2, lg - 2)
+        return min(20, c)
     return max(2, min(16, lg - 6))
 
 

@@ -41,6 +41,8 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp, uint32_t b
         // the window can grow until ~100 entries per bucket remain.  c = 17 buys nothing (W = 16).
         if (c == 0) {
             c = lg > 2 ? lg - 2 : 2;
+            if (lg == 20) c = 19;     // 14 windows instead of 15 pay for four times the buckets only here (2^20: 9.40 -> 9.16 ms per proof;
+                                      // 2^16 .. 2^19 and 2^21 measured neutral or worse with a wider window)
             if (batch > 1) c++;       // a batch shares the fixed costs of a set of launches: one window fewer pays (2^16 x 8: 0.76 -> 0.69 ms per proof)
         }
         if (c > 20) c = 20;
