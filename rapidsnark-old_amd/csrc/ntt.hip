@@ -1,20 +1,12 @@
-// BN254-Fr radix-2 NTT for gfx950 — replaces ffiasm FFT<Fr>::fft/ifft
-// (call sites src/groth16.cpp:102,115,120,133,139,152) and the coset shift loops
-// (src/groth16.cpp:107-110,125-128,144-147).
-//
-// MI355X design (not the reference's bit-reverse + log n full sweeps over RAM):
-//   * the inverse transform runs decimation-in-frequency (natural -> bit-reversed), the
-//     forward one decimation-in-time (bit-reversed -> natural); the coset shift and 1/n
-//     are applied in bit-reversed position from one table => no permutation pass at all.
-//   * each launch covers up to 11 butterfly stages on a 64 KiB LDS tile (2048 elements,
-//     limb-plane SoA so lane-consecutive elements hit distinct banks); upper-bit passes
-//     gather 2^q-element contiguous runs (>= 256 B) so HBM accesses stay coalesced.
-//     2^22 points = 3 launches instead of 22 sweeps.
-//   * a/b/c are transformed in one launch (blockIdx.y).
-//   * arithmetic: 9x29-bit signed limbs (field29.hpp, 2x the Montgomery-product rate of the 8x32
-//     form); HBM keeps canonical 256-bit words in the 2^261 Montgomery form, LDS holds 9 limb planes
-//     (72 KiB per 2048-element tile); the coset*1/n table is applied as the first DIT pass loads.
-// The butterflies are Montgomery-multiply bound (VALU), see DESIGN.md.
+// BN254-Fr transforms that are NOT on the proof path of an unpartitioned prover (that one is nttpair.hip):
+//   * k_ntt_cross / k_chunk_move : the log2(G) stages over the TOP index bits of a transform partitioned across G = 2/4/8
+//     GPUs (one radix-G butterfly per block offset, full-size twiddle tables) and the block <-> exchange-buffer moves;
+//   * k_ntt_pass (radix-2, one LDS round trip per stage, no bit-reversal pass: inverse = DIF, forward = DIT, the coset
+//     table multiplied in as the first forward pass loads) : rounds 1-2's transform, kept behind the stand-alone operator
+//     zk_fr_ntt (ffiasm FFT<Fr>::fft/ifft, call sites src/groth16.cpp:102,115,120,133,139,152) and for blocks of fewer
+//     than eight elements;
+//   * the pointwise helpers (abc -> h of src/groth16.cpp:158-163, Montgomery-radix conversion) and the radix-2 tables.
+// Arithmetic: 9x29-bit signed limbs (field29.hpp); HBM keeps canonical 256-bit words in the 2^261 Montgomery form.
 #include <stdlib.h>
 #include "kernels.hpp"
 #include "hipcheck.hpp"
