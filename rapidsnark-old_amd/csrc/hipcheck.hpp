@@ -5,6 +5,7 @@
 // code + zk_last_error() (nothing throws across the boundary).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdexcept>
 #include <string>
 
@@ -17,6 +18,20 @@ struct HipError : std::runtime_error {
 inline void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) throw HipError(std::string(what) + ": " + hipGetErrorString(e));
 }
+
+// Once per DEVICE: a function attribute set through hipFuncSetAttribute belongs to the current device's copy of the
+// kernel, and one process may drive eight devices (zk_multi_prover, the server's replicas).  need() is true until
+// done() has run on the calling thread's current device; two threads racing on one device both set the attribute.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static uint64_t bit() {
+        int d = 0;
+        hip_check(hipGetDevice(&d), "hipGetDevice");
+        return 1ull << (d & 63);
+    }
+    bool need() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+    void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 }   // namespace zk
 

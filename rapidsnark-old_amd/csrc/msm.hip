@@ -1111,12 +1111,12 @@ MsmSortSizes msm_sort_sizes(uint64_t n, MsmPlan p) {
 
 static inline size_t bin_scatter_lds_bytes() { return (size_t)(2 * BIN_MAX + 2 * bin_span() + bin_span() / 2 + 1) * 4; }
 static void sort_lds_attr() {
-    static bool attr_set = false;
-    if (attr_set) return;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
+    static PerDeviceOnce attr;
+    if (!attr.need()) return;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950), on every device
     ZK_HIP(hipFuncSetAttribute((const void *)k_bin_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr.done();
 }
 
 // digits -> bin partition -> per-bin LDS histograms -> scan -> LDS-ranked scatter -> compact bucket offsets

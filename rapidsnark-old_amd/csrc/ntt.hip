@@ -182,13 +182,13 @@ static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *t
     uint32_t T = t + q;
     uint32_t tiles = 1u << (local_logn - T);
     size_t shmem = (size_t)36 << T;     // 9 limb planes; 72 KiB at T = 11 (opt-in above 64 KiB)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    if (attr.need()) {
         ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_pass<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr.done();
     }
     if (ntt_threads() == 512u)
         hipLaunchKernelGGL((k_ntt_pass<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, tw, premul, logn, lo, t, q);

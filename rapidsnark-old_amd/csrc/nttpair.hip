@@ -497,6 +497,18 @@ void NttPair::release() {
     tinv = tfwd = dtab = t2inv = t2fwd = nullptr;
 }
 
+// the passes use 72 KiB (2048-element tiles) or 144 KiB (4096) of dynamic LDS: above 64 KiB a kernel needs the opt-in
+static void lds_opt_in() {
+    static PerDeviceOnce attr;
+    if (!attr.need()) return;
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr.done();
+}
+
 template <bool DIF>
 static void run_outer(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, uint32_t lo, uint32_t tt, const Fr *tab, uint32_t tab_bits,
                       hipStream_t s) {
@@ -512,15 +524,7 @@ static void run_outer(Fr *data, uint64_t stride, uint32_t batch, const NttPair &
     o.tab_mask = (1u << tab_bits) - 1u;
     o.plan = plan_windows(o.q, VB, VB);
     const uint32_t tiles = (uint32_t)((1ull << tb.L) >> VB);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    lds_opt_in();
     if (VB == 12) {
         const size_t shmem = (size_t)9 * 4096 * 4;
         hipLaunchKernelGGL((k_ntt_outer<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, o);
@@ -541,13 +545,7 @@ void launch_ntt_coset_pair(Fr *data, uint64_t stride, uint32_t batch, const NttP
         run_outer<true>(data, stride, batch, tb, tb.m, t, nullptr, 0, s);
     }
     {
-        if (!tb.ngroups) {          // (the attribute is set by run_outer otherwise)
-            static bool attr_set = false;
-            if (!attr_set) {
-                ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
-        }
+        lds_opt_in();
         PairDev d;
         memset(&d, 0, sizeof d);
         d.m = tb.m;

@@ -236,6 +236,7 @@ void FullProver::abort() {
                 j->status = aborted;
                 j->canceled = true;
                 j->wtns.reset();
+                std::string().swap(j->input);      // the job stays in `jobs` for status polls, its request body need not
             }
             q->clear();
         }

@@ -93,7 +93,7 @@ static void handle(int fd, FullProver &fp, std::string &buf) {
     if (qm != std::string::npos) target.resize(qm);
 
     size_t clen = 0;
-    bool expect100 = false;
+    bool expect100 = false, chunked = false;
     const bool http11 = reqline.size() >= 8 && reqline.compare(reqline.size() - 8, 8, "HTTP/1.1") == 0;
     bool keep = http11;                          // HTTP/1.1: persistent unless the client says close; 1.0: the other way round
     size_t pos = le == std::string::npos ? head.size() : le + 2;
@@ -107,10 +107,12 @@ static void handle(int fd, FullProver &fp, std::string &buf) {
             while (!val.empty() && val[0] == ' ') val.erase(0, 1);
             if (key == "content-length") clen = (size_t)strtoull(val.c_str(), nullptr, 10);
             if (key == "expect" && lower(val) == "100-continue") expect100 = true;
+            if (key == "transfer-encoding" && lower(val) != "identity") chunked = true;
             if (key == "connection") keep = lower(val) == "keep-alive" ? true : (lower(val) == "close" ? false : keep);
         }
         pos = e + 2;
     }
+    if (chunked) return respond(fd, 501, "Not Implemented", "Transfer-Encoding is not supported: send Content-Length", "text/plain");   // (closes: the body cannot be skipped)
     if (clen > kMaxRequest) return respond(fd, 413, "Request Entity Too Large", "", nullptr);
     std::string body = buf.substr(hdr_end + 4);
     if (expect100 && body.size() < clen) send_all(fd, "HTTP/1.1 100 Continue\r\n\r\n");
@@ -143,10 +145,10 @@ static void handle(int fd, FullProver &fp, std::string &buf) {
     if (method == "POST" && target.rfind("/input/", 0) == 0 && target.size() > 7 && target.find('/', 7) == std::string::npos) {
         if (fp.queueMode()) {      // ZKHIP_QUEUE=n: requests queue up instead of replacing each other
             uint64_t id = 0;
-            if (!fp.enqueue(body, target.substr(7), id)) return respond(fd, 503, "Service Unavailable", "{\"error\":\"queue full\"}", "application/json");
+            if (!fp.enqueue(std::move(body), target.substr(7), id)) return respond(fd, 503, "Service Unavailable", "{\"error\":\"queue full\"}", "application/json");
             return respond(fd, 200, "OK", "{\"job\":" + std::to_string(id) + "}", "application/json");
         }
-        fp.startProve(body, target.substr(7));
+        fp.startProve(std::move(body), target.substr(7));
         return respond(fd, 200, "OK", "", nullptr);
     }
     respond(fd, 404, "Not Found", "Could not find a matching route", "text/plain");
@@ -213,7 +215,12 @@ int main(int argc, char **argv) {
                     bool keep = true;
                     if (readable || !c.carry.empty()) {
                         do {
-                            handle(c.fd, fullProver, c.carry);
+                            try {
+                                handle(c.fd, fullProver, c.carry);
+                            } catch (std::exception &e) {     // (out of memory for a body, a failing file write): this request fails, the server stays
+                                t_keep = false;
+                                respond(c.fd, 500, "Internal Server Error", e.what(), "text/plain");
+                            }
                             keep = t_keep;
                         } while (keep && c.carry.find("\r\n\r\n") != std::string::npos);
                         c.last = now;

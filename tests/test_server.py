@@ -345,6 +345,12 @@ def test_keep_alive_connections_and_in_process_witness(tmp_path):
         r = c.getresponse()
         assert r.status == 200 and r.getheader("Connection") == "close"
         r.read()
+        # a chunked body is refused (the front end only frames by Content-Length) and the connection is closed, not misparsed
+        c2 = http.client.HTTPConnection("127.0.0.1", port, timeout=30)
+        c2.request("POST", "/input/" + name, body=iter([b'{"in":', b' 1}']), headers={"Transfer-Encoding": "chunked"})
+        r = c2.getresponse()
+        assert r.status == 501 and r.getheader("Connection") == "close"
+        r.read()
         assert srv.poll() is None
     finally:
         srv.terminate()
