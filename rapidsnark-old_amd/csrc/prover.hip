@@ -276,13 +276,19 @@ struct zk_prover {
         hipStream_t stream = nullptr, stream2 = nullptr;
         DevBuf<Fr> abc, h;
         SortBufs sort_h;
-        // the buffers (~1 GiB per lane at 2^22) appear the first time a proof runs on the lane, like the proof slots: the
-        // one-shot CLI and the shards of a sharded proof never use more than lane 0
+        // the streams (a hardware queue each: ~8 ms to create) and the buffers (~1 GiB per lane at 2^22) appear the first
+        // time a proof runs on the lane, like the proof slots: the one-shot CLI and the shards of a sharded proof never
+        // use more than lane 0
         uint64_t n_abc = 0, n_h = 0, nh_sort = 0;
         uint32_t wbits = 0, batch = 1;
-        bool precomp = false;
+        bool precomp = false, one_stream = false;
         void ensure() {
             if (abc.p) return;
+            if (!stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+                if (one_stream) stream2 = stream;
+                else HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+            }
             abc.alloc(n_abc);
             h.alloc(n_h);
             sort_h.alloc(nh_sort, wbits, precomp, batch);
@@ -327,7 +333,7 @@ struct zk_prover {
     ~zk_prover() {
         // proofs may still be in flight (submitted, never collected): drain before anything is released
         for (auto &x : extra)
-            if (x) { (void)hipStreamSynchronize(x->stream); (void)hipStreamSynchronize(x->stream2); }
+            if (x && x->stream) { (void)hipStreamSynchronize(x->stream); (void)hipStreamSynchronize(x->stream2); }
         for (hipStream_t st : {stream_h2d, stream, stream2, tail_pool[0], tail_pool[1], tail_pool[2], tail_pool[3], tail_pool[4], stream_fin})
             if (st) (void)hipStreamSynchronize(st);
         if (ev_ext_in) (void)hipEventDestroy(ev_ext_in);
@@ -667,11 +673,8 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         if (p->part || getenv("ZKHIP_SERIAL")) lanes = 1;
         for (int l = 1; l < lanes; l++) {
             auto x = std::make_unique<zk_prover::LaneExtra>();
-            HIP_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
             const char *ls = getenv("ZKHIP_LANE_STREAMS");
-            const bool one_stream = ls && atoi(ls) == 1;
-            if (one_stream) x->stream2 = x->stream;
-            else HIP_TRY(hipStreamCreateWithFlags(&x->stream2, hipStreamNonBlocking));
+            x->one_stream = ls && atoi(ls) == 1;
             x->n_abc = 3 * p->nloc * p->batch;
             x->n_h = p->nloc * p->batch;
             x->nh_sort = nh;

@@ -49,7 +49,7 @@ def main():
                 evict(zpath)
                 evict(wpath)
             print("=== %s page cache" % ("COLD" if i == 0 else "warm"))
-            env = dict(os.environ, ZKHIP_VERBOSE="1", ZKHIP_PRECOMP=mode)
+            env = dict(os.environ, ZKHIP_VERBOSE="1", ZKHIP_PRECOMP=mode, ZKHIP_T0=repr(time.time()))
             t0 = time.perf_counter()
             out = subprocess.run([exe, zpath, wpath, os.path.join(d, "p.json"), os.path.join(d, "q.json")], capture_output=True, text=True, env=env)
             dt = time.perf_counter() - t0
