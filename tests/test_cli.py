@@ -13,7 +13,7 @@ PROVER = os.path.join(ROOT, "rapidsnark-old_amd", "prover")
 def run(*args, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    return subprocess.run([PROVER, *args], capture_output=True, text=True, env=e, timeout=300)
+    return subprocess.run([PROVER, *args], capture_output=True, text=True, errors="replace", env=e, timeout=300)
 
 
 def test_usage_and_exit_code():
@@ -127,3 +127,38 @@ def test_shipped_library_reads_no_probe_variable():
     blob = open(os.path.join(ROOT, "rapidsnark-old_amd", "libzkhip.so"), "rb").read()
     for name in _RETIRED_PROBES:
         assert name.encode() not in blob, name
+
+
+def test_damaged_files_end_in_an_error_exit_never_in_a_signal(tmp_path):
+    """Truncated files, flipped header bytes, section sizes that point past the end of the file: the reference indexes
+    sections blindly (quirks Q1/Q8); here every such input must end with exit code 255 and a message (or, when the damage
+    only hit curve points or scalars, with a proof) — never with a signal.  Runs without a GPU too (the files are parsed
+    before the device is asked for)."""
+    import random
+    rng = random.Random(20260928)
+    zkey, wtns = golden_bytes("r1cs_n8", "circuit.zkey"), golden_bytes("r1cs_n8", "witness.wtns")
+    cases = []
+    for _ in range(14):
+        cases.append(("z", zkey[:rng.randrange(0, len(zkey))]))
+        cases.append(("w", wtns[:rng.randrange(0, len(wtns))]))
+    for _ in range(16):                                      # one byte of the header / section table / first sections changed
+        for kind, blob in (("z", zkey), ("w", wtns)):
+            b = bytearray(blob)
+            i = rng.randrange(0, min(len(b), 400))
+            b[i] = rng.choice([0, 1, 0x7f, 0x80, 0xff, b[i] ^ 0x40])
+            cases.append((kind, bytes(b)))
+    for kind, blob in (("z", zkey), ("w", wtns)):            # every section size field in turn: huge
+        pos, nsec = 12, int.from_bytes(blob[8:12], "little")
+        for _ in range(nsec):
+            size = int.from_bytes(blob[pos + 4:pos + 12], "little")
+            b = bytearray(blob)
+            b[pos + 4:pos + 12] = (1 << 62).to_bytes(8, "little")
+            cases.append((kind, bytes(b)))
+            pos += 12 + size
+    for n, (kind, blob) in enumerate(cases):
+        zp, wp = tmp_path / "c.zkey", tmp_path / "w.wtns"
+        zp.write_bytes(blob if kind == "z" else zkey)
+        wp.write_bytes(blob if kind == "w" else wtns)
+        r = run(str(zp), str(wp), str(tmp_path / "p.json"), str(tmp_path / "q.json"))
+        assert r.returncode in (0, 255), (n, kind, len(blob), r.returncode, r.stderr[-300:])
+        assert r.returncode == 0 or r.stderr.strip(), (n, kind, "silent failure")
