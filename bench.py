@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--chain", choices=["auto", "partitioned", "replicated"], default="auto",
                     help="N > 1: partition the A.w/B.w rows and the NTTs across the ranks (auto: when N is 2, 4 or 8) or replicate them")
     ap.add_argument("--verify", type=int, default=1, help="N > 1: check one sharded proof against an unsharded prover on rank 0 (outside the timed region)")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the `replicas` leg (every GPU proving its own proofs, no collective)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-2p20", action="store_true", help="skip the also_2p20 leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--cpu-budget-s", type=float, default=36.0)
@@ -344,6 +345,13 @@ def run(args):
             verified = ref.prove_host(wits_host[0], vr, vs) == sharded
             ref.lib.zk_prover_destroy(ref.h)
 
+    # N > 1, after the headline: the OTHER way to use N GPUs — every rank proves its own proofs on its own GPU with an
+    # unsharded prover, no collective in the data path (what proverServer's throughput mode runs; "replicas
+    # only").  Same timing rules: barrier + synchronize on both sides, max over ranks; value = N * K proofs / that time.
+    replicas = None
+    if world > 1 and not args.no_replicas:
+        replicas = replicas_leg(zk, wl, local_rank, k, wits_host, args.steps, bool(args.precomp), dist, xdev, torch, world)
+
     latency_ms = latency_host_ms = None
     lone = {}
     if world == 1:                        # outside the timed region: strictly one proof at a time
@@ -430,10 +438,46 @@ def run(args):
         out["exchange_backend"] = "gloo via the host (ZK_BENCH_SHARE_GPU test hook)" if share else "nccl (RCCL over xGMI)"
         if chain is not None:
             out["exchange_ms"] = chain.phase_times_ms()
+        if replicas is not None:
+            out["replicas"] = replicas
     prover.lib.zk_prover_destroy(prover.h)
     if dist:
         dist.destroy_process_group()
     return out
+
+
+def replicas_leg(zk, wl, device, k, wits_host, steps, precomp, dist, xdev, torch, world):
+    """N > 1: K proofs per GPU on N independent unsharded provers (host witnesses, the default number in flight, one host
+    thread per rank) -> the line's `replicas` object.  Weak scaling: per-GPU work is fixed as N grows."""
+    p = ProverFromView(zk, wl, device=device, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=precomp)
+    depth = default_depth(k, False, 1)
+    for i in range(depth):                      # untimed: every proof slot exists afterwards
+        p.submit_host(wits_host[i % len(wits_host)])
+    for i in range(depth):
+        p.collect()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    flying = 0
+    for i in range(steps):
+        p.submit_host(wits_host[i % len(wits_host)])
+        flying += 1
+        if flying == depth:
+            p.collect()
+            flying -= 1
+    while flying:
+        p.collect()
+        flying -= 1
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=xdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    p.lib.zk_prover_destroy(p.h)
+    return {"value": round(world * steps / dt, 4), "unit": "proofs/s", "scaling": "weak", "steps_per_gpu": steps, "ms_per_step_per_gpu": round(dt / steps * 1e3, 3),
+            "proofs_in_flight_per_gpu": depth,
+            "note": "every GPU proves its own proofs on an unsharded prover (no collective in the data path; proverServer's throughput mode); "
+                    "the headline above is ONE proof at a time across all GPUs (north_star: MSMs and NTT partitioned)"}
 
 
 def default_depth(k, in_hbm, world=1):

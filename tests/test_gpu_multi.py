@@ -179,3 +179,5 @@ def test_bench_multi_rank_path_on_one_gpu(ranks, k):
     assert set(d["exchange_ms"]) == {"witness_all_gather", "all_to_all_1_to_cross_inverse", "all_to_all_2_to_local",
                                      "all_to_all_3_to_cross_forward", "all_to_all_4_to_finish"}
     assert d["value"] > 0 and d["scaling"] == "strong"
+    # the other use of N GPUs, timed in the same run: independent replicas, weak scaling
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0 and d["replicas"]["steps_per_gpu"] == 4
