@@ -843,6 +843,11 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     DeviceGuard g(p->device);
     if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("too many proofs in flight (ZK_MAX_IN_FLIGHT): collect one first");
     if (p->phase_open >= 0) throw std::invalid_argument("a proof is still being submitted phase by phase");
+    // nothing in flight: start over at slot 0 — a caller that proves one at a time (zk_prove, the reference's contract) then
+    // lives in ONE slot on lane 0 instead of walking through all eight (each with ~1 GiB of buffers at 2^22, a pinned
+    // staging copy and, per lane, two streams its first use has to create: the first eight proofs of a prover paid
+    // 10-20 ms each for that).  (Not while a graph is being captured: submit_graph has chosen the slot.)
+    if (p->in_flight == 0 && !p->capturing) p->next_submit = p->next_collect = 0;
     const int si = (int)(p->next_submit % ZK_MAX_IN_FLIGHT);
     alloc_slot(p, si);
     PhaseCtx c(p, si);
@@ -1056,6 +1061,7 @@ struct PhaseAbort {
 static void submit_graph(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32) {
     if (p->in_flight >= ZK_MAX_IN_FLIGHT) throw std::invalid_argument("too many proofs in flight (ZK_MAX_IN_FLIGHT): collect one first");
     if (p->phase_open >= 0) throw std::invalid_argument("a proof is still being submitted phase by phase");
+    if (p->in_flight == 0) p->next_submit = p->next_collect = 0;      // (see phase_front)
     const int si = (int)(p->next_submit % ZK_MAX_IN_FLIGHT);
     alloc_slot(p, si);
     PhaseCtx c(p, si);
