@@ -232,6 +232,7 @@ struct zk_prover {
         // k+1's upload runs (on its own stream) while proof k is still computing.
         DevBuf<Fr> wtns_dev;              // batch x nVars
         uint8_t *wtns_pin = nullptr;
+        uint8_t *pin_ring = nullptr;          // two upload pieces of pinned memory: the staging of a lone proof on a slot that has no wtns_pin yet
         StageJob stage[ZK_MAX_BATCH];
         StageJob stage_chunk[16];        // a large pageable witness is staged and uploaded in pieces on two streams
         hipEvent_t ev_h2d_b = nullptr;
@@ -258,6 +259,7 @@ struct zk_prover {
             if (w1) (void)hipHostFree(w1);
             if (w2) (void)hipHostFree(w2);
             if (wtns_pin) (void)hipHostFree(wtns_pin);
+            if (pin_ring) (void)hipHostFree(pin_ring);
             if (ev_h2d) (void)hipEventDestroy(ev_h2d);
             if (ev_h2d_b) (void)hipEventDestroy(ev_h2d_b);
             if (ev_h2d_start) (void)hipEventDestroy(ev_h2d_start);
@@ -736,7 +738,6 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
         (void)hipGetLastError();                       // an unregistered pointer is reported as an error: not one
         const uint8_t *src = h_wtns[k];
         if (!pinned) {
-            if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes * p->batch, hipHostMallocDefault));
             if (count == 1 && bytes >= ((size_t)32 << 20) && p->in_flight == 0) {
                 // A large pageable witness (128 MiB at 2^22): pieces alternate between two upload streams, so the staging of
                 // piece i+1 (host function: four threads of memcpy) runs beside the DMA of piece i.  Staging and DMA of the whole
@@ -744,6 +745,10 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
                 // Only when no other proof is in flight: in a full pipeline the upload is hidden anyway and the sixteen extra
                 // stream operations cost 1 % of the period.
                 const size_t npc = 8, per = ((bytes / npc) + 4095) & ~(size_t)4095;
+                // staging: the slot's full-size pinned copy when a pipelined submission has made one, else a ring of two pieces
+                // (one per stream: piece c + 2 is staged after the DMA of piece c, which stream order guarantees) — the first
+                // proof of a process (the one-shot CLI's only one) no longer waits ~20 ms for 128 MiB of pinned memory
+                if (!q.wtns_pin && !q.pin_ring) HIP_TRY(hipHostMalloc((void **)&q.pin_ring, 2 * per, hipHostMallocDefault));
                 if (!q.ev_h2d_b) HIP_TRY(hipEventCreateWithFlags(&q.ev_h2d_b, hipEventDisableTiming));
                 hipStream_t sb = p->stream_fin;          // idle: nothing is in flight (no stream of its own: hardware queues are few)
                 if (src_ready) HIP_TRY(hipStreamWaitEvent(sb, src_ready, 0));
@@ -754,14 +759,16 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
                 for (size_t c = 0, off = 0; off < bytes; c++, off += per) {
                     const size_t len = off + per < bytes ? per : bytes - off;
                     hipStream_t st = (c & 1) ? sb : sh;
-                    q.stage_chunk[c] = StageJob{q.wtns_pin + off, h_wtns[k] + off, len};
+                    uint8_t *stg = q.wtns_pin ? q.wtns_pin + off : q.pin_ring + (c & 1) * per;
+                    q.stage_chunk[c] = StageJob{stg, h_wtns[k] + off, len};
                     HIP_TRY(hipLaunchHostFunc(st, stage_job_run, &q.stage_chunk[c]));
-                    HIP_TRY(hipMemcpyAsync(dst + off, q.wtns_pin + off, len, hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(dst + off, stg, len, hipMemcpyHostToDevice, st));
                 }
                 HIP_TRY(hipEventRecord(q.ev_h2d_b, sb));
                 HIP_TRY(hipStreamWaitEvent(sh, q.ev_h2d_b, 0));
                 continue;
             }
+            if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, bytes * p->batch, hipHostMallocDefault));
             q.stage[k] = StageJob{q.wtns_pin + (size_t)k * bytes, h_wtns[k], bytes};
             static const bool sync_stage = probe_env("ZKHIP_STAGE_SYNC") != nullptr;      // tuning aid: stage inside the call
             if (sync_stage) stage_job_run(&q.stage[k]);
