@@ -504,37 +504,59 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         }
     }
-    // ZKHIP_SERIAL=1 (profiling aid): one stream, so that rocprofv3 kernel durations are not
-    // inflated by the other stream's kernels sharing the CUs.
-    if (getenv("ZKHIP_SERIAL")) p->stream2 = p->stream;
-    else HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
-    {
-        // Follow-up streams (highest priority) for the partial merges and bucket reductions: on
-        // the streams of their MSMs these small kernels queue behind the next level-1 launch and
-        // pile up after the last one.  Measured with two proofs in flight: 2^22 39.7 -> 39.1 ms
-        // (same box), 2^20 15.8 -> 13.5 ms, a shard of 8 at 2^22 12.4 -> 11.3 ms; one proof at a
-        // time it is neutral from 2^20 up (2^18: 7.6 -> 8.0 ms).  ZKHIP_TAIL=0 turns them off.
-        // Two follow-up streams (the tails of stream 2's MSMs on one, of stream 1's on the other).  One per
-        // MSM (ZKHIP_TAIL=5) was measured neutral at every size from 2^14 to 2^22 (tools/ab_tailstreams.sh)
-        // — at most four kernels ever run concurrently in a proof's trace, whatever the number of streams —
-        // and costs three more hardware queues.
-        const char *e = getenv("ZKHIP_TAIL");
-        int ntail = e ? atoi(e) : 2;
-        if (getenv("ZKHIP_SERIAL")) ntail = 0;
-        if (ntail != 0 && ntail != 5) ntail = 2;
-        p->tail_streams = ntail;
-        if (ntail) {
-            int lo_pr = 0, hi_pr = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pr, &hi_pr));
-            for (int i = 0; i < ntail; i++) HIP_TRY(hipStreamCreateWithPriority(&p->tail_pool[i], hipStreamNonBlocking, hi_pr));
-            for (int m = 0; m < 5; m++) p->tail[m] = ntail == 5 ? p->tail_pool[m] : p->tail_pool[(m == 2 || m == 3) ? 1 : 0];
+    // The other five streams (a hardware queue each: 8-19 ms apiece, profiles/r03v_hip_init_probe.txt) are not used before
+    // the first proof: a helper thread creates them while this one uploads the key (joined before create returns).
+    struct SideStreams {
+        std::thread th;
+        std::exception_ptr err;
+        ~SideStreams() {
+            if (th.joinable()) th.join();
         }
-    }
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream_fin, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream_h2d, hipStreamNonBlocking));
+        void finish() {
+            if (th.joinable()) th.join();
+            if (err) std::rethrow_exception(err);
+        }
+    } side;
+    zk_prover *const pp = p.get();
+    side.th = std::thread([pp, dev, &side] {
+        try {
+            zk_prover *const p = pp;
+            HIP_TRY(hipSetDevice(dev));
+            // ZKHIP_SERIAL=1 (profiling aid): one stream, so that rocprofv3 kernel durations are not
+            // inflated by the other stream's kernels sharing the CUs.
+            if (getenv("ZKHIP_SERIAL")) p->stream2 = p->stream;
+            else HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+            {
+                // Follow-up streams (highest priority) for the partial merges and bucket reductions: on
+                // the streams of their MSMs these small kernels queue behind the next level-1 launch and
+                // pile up after the last one.  Measured with two proofs in flight: 2^22 39.7 -> 39.1 ms
+                // (same box), 2^20 15.8 -> 13.5 ms, a shard of 8 at 2^22 12.4 -> 11.3 ms; one proof at a
+                // time it is neutral from 2^20 up (2^18: 7.6 -> 8.0 ms).  ZKHIP_TAIL=0 turns them off.
+                // Two follow-up streams (the tails of stream 2's MSMs on one, of stream 1's on the other).  One per
+                // MSM (ZKHIP_TAIL=5) was measured neutral at every size from 2^14 to 2^22 (tools/ab_tailstreams.sh)
+                // — at most four kernels ever run concurrently in a proof's trace, whatever the number of streams —
+                // and costs three more hardware queues.
+                const char *e = getenv("ZKHIP_TAIL");
+                int ntail = e ? atoi(e) : 2;
+                if (getenv("ZKHIP_SERIAL")) ntail = 0;
+                if (ntail != 0 && ntail != 5) ntail = 2;
+                p->tail_streams = ntail;
+                if (ntail) {
+                    int lo_pr = 0, hi_pr = 0;
+                    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pr, &hi_pr));
+                    for (int i = 0; i < ntail; i++) HIP_TRY(hipStreamCreateWithPriority(&p->tail_pool[i], hipStreamNonBlocking, hi_pr));
+                    for (int m = 0; m < 5; m++) p->tail[m] = ntail == 5 ? p->tail_pool[m] : p->tail_pool[(m == 2 || m == 3) ? 1 : 0];
+                }
+            }
+            HIP_TRY(hipStreamCreateWithFlags(&p->stream_fin, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&p->stream_h2d, hipStreamNonBlocking));
+        } catch (...) {
+            side.err = std::current_exception();
+        }
+    });
     p->wbits = wbits;
     hipStream_t s = p->stream;
-    clk.lap("device + streams", s);
+    clk.lap("device + first stream", s);
     StreamUploader up(s);
 
     // --- this shard's contiguous slices of the witness indices and of the domain
@@ -690,6 +712,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         p->use_graph = ge && atoi(ge) != 0 && !p->part && p->batch == 1 && !(p->flags & ZK_FLAG_TIMINGS) && !getenv("ZKHIP_SERIAL");
     }
     HIP_TRY(hipStreamSynchronize(s));   // host image may be released after return
+    side.finish();
     clk.lap(p->precomp ? "window pre-computation" : "finish", s);
     *out = p.release();
 }
