@@ -208,6 +208,7 @@ struct zk_prover {
     // overlap the tail of proof k (merges, reductions, D2H, host Horner + assembly).
     struct ProofSlot {
         bool allocated = false, busy = false;
+        bool use_tails = true;                // this proof's merges / reductions on the follow-up streams (decided at submit)
         SortBufs sort_w;
         DevBuf<G1Acc> buckets_g1;    // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
         DevBuf<G2Acc> buckets_g2;
@@ -527,17 +528,19 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             if (getenv("ZKHIP_SERIAL")) p->stream2 = p->stream;
             else HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
             {
-                // Follow-up streams (highest priority) for the partial merges and bucket reductions: on
-                // the streams of their MSMs these small kernels queue behind the next level-1 launch and
-                // pile up after the last one.  Measured with two proofs in flight: 2^22 39.7 -> 39.1 ms
-                // (same box), 2^20 15.8 -> 13.5 ms, a shard of 8 at 2^22 12.4 -> 11.3 ms; one proof at a
-                // time it is neutral from 2^20 up (2^18: 7.6 -> 8.0 ms).  ZKHIP_TAIL=0 turns them off.
+                // Follow-up streams (highest priority) for the partial merges and bucket reductions of a SHARDED prover: on the
+                // streams of their MSMs these small kernels queue behind the next level-1 launch and pile up after the last
+                // one — with two proofs in flight the rank-0 share of 8 shards at 2^22 is 6.2-6.5 ms with them, 6.6 without
+                // (round 1, before there were lanes: 2^20 unsharded 15.8 -> 13.5 ms).  An unsharded prover gets NONE since
+                // round 3: its lanes do the same job (pipelined period equal with and without at 2^16 ... 2^22), and the
+                // mere existence of the two high-priority queues costs a lone proof 2 % (2^22 synchronous 39.5 -> 38.8 ms,
+                // 2^20 12.9 -> 12.0 ms, three-way same-box A/B).  ZKHIP_TAIL=0/2/5 overrides.
                 // Two follow-up streams (the tails of stream 2's MSMs on one, of stream 1's on the other).  One per
                 // MSM (ZKHIP_TAIL=5) was measured neutral at every size from 2^14 to 2^22 (tools/ab_tailstreams.sh)
                 // — at most four kernels ever run concurrently in a proof's trace, whatever the number of streams —
                 // and costs three more hardware queues.
                 const char *e = getenv("ZKHIP_TAIL");
-                int ntail = e ? atoi(e) : 2;
+                int ntail = e ? atoi(e) : (p->shard_count > 1 ? 2 : 0);
                 if (getenv("ZKHIP_SERIAL")) ntail = 0;
                 if (ntail != 0 && ntail != 5) ntail = 2;
                 p->tail_streams = ntail;
@@ -840,8 +843,10 @@ struct PhaseCtx {
         const int lane = si % p->lanes;
         if (lane == 0) {
             s = p->stream; s2 = p->stream2; sf = p->stream_fin;
-            for (int m = 0; m < 5; m++) tail[m] = p->tail[m];
-            ntails = p->tail_streams;
+            if (q.use_tails) {
+                for (int m = 0; m < 5; m++) tail[m] = p->tail[m];
+                ntails = p->tail_streams;
+            }
             abc = p->abc_use; h = p->h.p; sort_h = &p->sort_h;
         } else {
             zk_prover::LaneExtra &x = *p->extra[lane - 1];
@@ -880,6 +885,12 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     if (p->in_flight == 0 && !p->capturing) p->next_submit = p->next_collect = 0;
     const int si = (int)(p->next_submit % ZK_MAX_IN_FLIGHT);
     alloc_slot(p, si);
+    // Follow-up streams only for a proof that is submitted while another one is in flight: they let the next level-1 launch
+    // start beside the merges and reductions of the previous MSM — worth 2 % of a sharded prover's period with two in flight —
+    // but every hop to them is an event across hardware queues, and a LONE proof is faster without (same box, with / without:
+    // 2^22 synchronous 39.0-39.8 / 37.9-38.0 ms, 2^20 13.3 / 12.4 ms; rank-0 share of 8 shards one at a time 7.8-8.0 / 6.5 ms).
+    // (A captured graph keeps whatever its slot recorded.)
+    if (!p->capturing) p->slot[si].use_tails = p->in_flight > 0 || p->use_graph;
     PhaseCtx c(p, si);
     zk_prover::ProofSlot &q = c.q;
     bool staged = h_wtns != nullptr;
