@@ -7,6 +7,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <iostream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -156,7 +158,16 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     }
     if (batch > 1 && (o.flags & ZK_FLAG_PRECOMP)) o.batch = batch > ZK_MAX_BATCH ? ZK_MAX_BATCH : batch;
     zk_prover *h = nullptr;
-    if (zk_prover_create(&h, &v, &o) != 0) throw std::runtime_error(zk_last_error());
+    int rc = zk_prover_create(&h, &v, &o);
+    // window-precomputed tables are 13 x the table memory (2^26 constraints: > 288 GB): where they were only the DEFAULT
+    // (proverServer) and do not fit, the prover is created with the tables as they are in the zkey instead of not at all
+    if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !pc && strstr(zk_last_error(), "out of memory")) {
+        std::cerr << "window-precomputed tables do not fit the GPU's free memory: using the tables as in the zkey\n";
+        o.flags &= ~(uint32_t)ZK_FLAG_PRECOMP;
+        o.batch = 0;
+        rc = zk_prover_create(&h, &v, &o);
+    }
+    if (rc != 0) throw std::runtime_error(zk_last_error());
     return std::unique_ptr<Prover>(new Prover(h, o.batch));
 }
 

@@ -8,6 +8,7 @@ import shutil
 import socket
 import stat
 import subprocess
+import sys
 import time
 import urllib.error
 import urllib.request
@@ -407,3 +408,67 @@ def test_cancel_in_throughput_mode_drops_what_has_not_reached_a_gpu(tmp_path):
     finally:
         srv.terminate()
         srv.wait(10)
+
+
+@pytest.mark.gpu
+def test_server_falls_back_to_plain_tables_when_the_precomputed_ones_do_not_fit(zk, tmp_path):
+    """proverServer creates its provers with window-precomputed tables by default (13 x the table memory).  Where those do
+    not fit the GPU's free memory — here: a 2^20 key while another process holds all but 7 GiB of the HBM; in the field:
+    2^26 constraints — the prover is created with the tables as they are in the zkey instead, says so, and proves the same bytes."""
+    import struct
+    import numpy as np
+    from rapidsnark_old_amd import synth
+    from tools.cli_timing import binfile, R_MOD, Q_MOD
+    k = 20
+    wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes())
+    w = synth.make_witness(k, seed=3)
+    b = lambda name: np.asarray(wl[name]).tobytes()
+    sec2 = (struct.pack("<I", 32) + Q_MOD.to_bytes(32, "little") + struct.pack("<I", 32) + R_MOD.to_bytes(32, "little")
+            + struct.pack("<III", wl["nVars"], wl["nPublic"], wl["domainSize"])
+            + b("vk_alpha1") + b("vk_beta1") + b("vk_beta2") + b("vk_beta2") + b("vk_delta1") + b("vk_delta2"))
+    zpath, wpath = tmp_path / "big.zkey", tmp_path / "big.wtns"
+    binfile(str(zpath), b"zkey", 1, [(1, struct.pack("<I", 1)), (2, sec2), (3, bytes(64 * (wl["nPublic"] + 1))), (4, b("coefs")),
+                                     (5, b("pointsA")), (6, b("pointsB1")), (7, b("pointsB2")), (8, b("pointsC")), (9, b("pointsH")), (10, bytes(68))])
+    binfile(str(wpath), b"wtns", 2, [(1, struct.pack("<I", 32) + R_MOD.to_bytes(32, "little") + struct.pack("<I", wl["nVars"])), (2, np.asarray(w).tobytes())])
+    del wl
+    fixed = {"ZKHIP_FIXED_R": _le_hex(12345), "ZKHIP_FIXED_S": _le_hex(67890)}
+    # the reference bytes: the one-shot CLI (tables as in the zkey) with the same (r, s)
+    cli = subprocess.run([os.path.join(ROOT, "rapidsnark-old_amd", "prover"), str(zpath), str(wpath), str(tmp_path / "p.json"), str(tmp_path / "q.json")],
+                         env=dict(os.environ, **fixed), capture_output=True, text=True, timeout=300)
+    assert cli.returncode == 0, cli.stderr
+    hog = subprocess.Popen([sys.executable, "-c",
+                            "import time, torch\nfree, _ = torch.cuda.mem_get_info()\nx = torch.empty(free - (7 << 30), dtype=torch.uint8, device='cuda')\n"
+                            "print('held', flush=True)\ntime.sleep(300)\n"], stdout=subprocess.PIPE, text=True)
+    srv = None
+    try:
+        assert hog.stdout.readline().strip() == "held"
+        (tmp_path / "build").mkdir(exist_ok=True)
+        port = _free_port()
+        env = dict(os.environ, ZKHIP_QUEUE="4", ZKHIP_WORKERS="0", **fixed)
+        env.pop("ZKHIP_PRECOMP", None)
+        srv = subprocess.Popen([SERVER, str(port), str(zpath)], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        for _ in range(900):
+            try:
+                _http(port, "GET", "/status")
+                break
+            except (ConnectionError, urllib.error.URLError):
+                assert srv.poll() is None, srv.stderr.read().decode()
+                time.sleep(0.1)
+        code, body, _ = _http(port, "POST", "/witness/big", wpath.read_bytes())
+        assert code == 200
+        job = json.loads(body)["job"]
+        for _ in range(3000):
+            doc = json.loads(_http(port, "GET", "/status/%d" % job)[1])
+            if doc["status"] != "busy":
+                break
+            time.sleep(0.01)
+        assert doc["status"] == "success", doc
+        assert doc["proof"] == (tmp_path / "p.json").read_text() and doc["pubData"] == (tmp_path / "q.json").read_text()
+        srv.terminate()
+        err = srv.communicate(timeout=20)[1].decode()
+        srv = None
+        assert "do not fit the GPU's free memory" in err, err
+    finally:
+        hog.kill()
+        if srv is not None:
+            srv.kill()
