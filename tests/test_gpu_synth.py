@@ -208,3 +208,34 @@ def test_valid_key_at_scale_passes_trapdoor_check(zk, tmp_path, k, precomp):
     assert out.returncode == 0, out.stderr
     assert (tmp_path / "p.json").read_text() == zk.proof_to_json(proof)
     assert (tmp_path / "q.json").read_text() == zk.public_to_json(wit, wl["nPublic"])
+
+
+@pytest.mark.parametrize("k,n_vars,n_public", [(13, 5000, 7), (13, 8191, 1), (13, 12345, 40), (12, 4097, 0), (14, 16384 + 4096, 2)])
+@pytest.mark.parametrize("precomp", [False, True])
+def test_irregular_shapes_bit_exact_vs_c_oracle(zk, k, n_vars, n_public, precomp):
+    """Real circuits have nVars != domainSize and several public signals; the synthetic family has nVars = domainSize and
+    one.  Mid-size keys with fewer / more signals than domain rows, nPublic from 0 to 40, odd table lengths: the GPU
+    proof against the C restatement bit for bit (all five MSMs and the assembled proof), both table modes."""
+    import torch
+    from rapidsnark_old_amd import synth
+    n = 1 << k
+    big = _gpu_workload(zk, k + 1)                          # a pool of 2n valid points per table to cut the tables from
+    wl = dict(_gpu_workload(zk, k))
+    wl["nVars"], wl["nPublic"] = n_vars, n_public
+    for name, width in (("pointsA", 64), ("pointsB1", 64), ("pointsB2", 128)):
+        wl[name] = np.ascontiguousarray(np.asarray(big[name]).reshape(-1)[: n_vars * width])
+    wl["pointsC"] = np.ascontiguousarray(np.asarray(big["pointsC"]).reshape(-1)[: (n_vars - n_public - 1) * 64])
+    img = np.asarray(wl["coefs"]).copy()                    # u32 count + 44-byte records: fold the signal indices into [0, nVars)
+    rec = img[4:].view(synth.COEF_DTYPE)
+    rng = np.random.default_rng(k * 1000 + n_vars)
+    rec["s"] = np.where(rec["s"] < n_vars, rec["s"], rec["s"] % n_vars) if n_vars <= n else rng.integers(0, n_vars, size=rec.shape[0], dtype=np.uint32)
+    wl["coefs"] = img
+    w = synth.random_fr_bytes(rng, n_vars).reshape(-1).copy()
+    w[:32] = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
+    view = co.ZkeyView(wl)
+    p = _prover(zk, wl, precomp=precomp)
+    wd = torch.from_numpy(w).to("cuda:0")
+    r, s = 0x1357924680ACE, (1 << 200) + 99
+    assert p.prove_msm_dev(wd.data_ptr()) == co.prove_msm(view, w)
+    assert p.prove_dev(wd.data_ptr(), r, s) == co.prove(view, w, r, s)
+    p.lib.zk_prover_destroy(p.h)
