@@ -128,3 +128,23 @@ def test_eip196_public_vectors_on_the_gpu(zk):
     g1 = bn.g1_to_bytes(bn.G1.gen)
     assert zk.msm_g1(g1 + g1, one + one) == bn.g1_to_bytes(EIP196_2G)          # P = Q: the doubling branch of the mixed add
     assert zk.g1_mul(g1, 2) == bn.g1_to_bytes(EIP196_2G)
+
+
+def test_msm_scalars_at_and_above_the_group_order(zk):
+    """Scalars are raw 256-bit integers in the reference (multiMulByScalar takes bytes): r, r + 1, 2r + 5, 2^256 - 1 act as
+    their residues mod r, r - 1 as -1 — the digit recoding brings any 256-bit value below r first."""
+    r = bn.R_MOD
+    ks = [r, r + 1, r - 1, 2 * r + 5, (1 << 256) - 1, 5 * r + 123456789, 0, 1]
+    pts, _, _ = _chain_points(len(ks), 777)
+    want = None
+    for P, k in zip(pts, ks):
+        want = G1.add(want, G1.mul(P, k % r))
+    got = zk.msm_g1(b"".join(bn.g1_to_bytes(P) for P in pts), b"".join(int(k).to_bytes(32, "little") for k in ks))
+    assert got == bn.g1_to_bytes(want)
+    # the same scalars over a table long enough for the sorted path (every kernel of the pipeline), against their residues
+    n = 5000
+    pts, _, _ = _chain_points(n, 4321)
+    bases = b"".join(bn.g1_to_bytes(P) for P in pts)
+    rng = random.Random(11)
+    big = [rng.choice(ks[:6]) if i % 3 == 0 else rng.randrange(r, 1 << 256) for i in range(n)]
+    assert zk.msm_g1(bases, b"".join(k.to_bytes(32, "little") for k in big)) == zk.msm_g1(bases, b"".join((k % r).to_bytes(32, "little") for k in big))
