@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void k_csr_count(uint32_t *rowcount, uint32_t 
     const uint32_t nl = row_hi - row_lo;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoefs; i += st) {
         const uint32_t *r = rec + i * 11;
-        uint32_t m = r[0], c = r[1], sg = r[2];
-        if (m > 1u || c >= n || sg >= nVars) {
+        const uint32_t m = r[0] ? 1u : 0u, c = r[1], sg = r[2];      // the reference: (coefs[i].m == 0) ? a : b  (groth16.cpp:69)
+        if (c >= n || sg >= nVars) {
             atomicOr(err, 1u);
             continue;
         }
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void k_csr_fill(uint32_t *col, Fr *val, uint32
     const uint32_t nl = row_hi - row_lo;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoefs; i += st) {
         const uint32_t *r = rec + i * 11;
-        uint32_t m = r[0], c = r[1], sg = r[2];
-        if (m > 1u || c >= n || sg >= nVars || c < row_lo || c >= row_hi) continue;
+        const uint32_t m = r[0] ? 1u : 0u, c = r[1], sg = r[2];
+        if (c >= n || sg >= nVars || c < row_lo || c >= row_hi) continue;
         uint32_t pos = atomicAdd(&cursor[(uint64_t)m * nl + (c - row_lo)], 1u);
         col[pos] = sg;
         Fr v;
