@@ -969,7 +969,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out,
 // of a small proof's kernel time).  The c sums go to the host, whose serial Horner over c-1 bits costs
 // microseconds.  Used while a launch reduces at most 2^16 buckets (circuits up to 2^18 constraints); the chunked
 // form stays for the large sets, where work, not depth, is what counts.  In place: a block of size 2^m keeps T in its slot 0 and S_j in slot 1+j.
-#define BITS_RS 16u         // slots per block record in global memory (>= c <= 16)
+#define BITS_RS 18u         // slots per block record in global memory (>= c)
 template <class F>
 __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_block(ACCMEM *rec, XYZZ<F> *final_out, const ACCMEM *buckets,
                                                                          uint32_t nbuckets, uint32_t c, uint32_t nblk) {

@@ -1,5 +1,5 @@
 """Per-rank cost of a sharded proof on ONE GPU: rank 0's share of a world of G (no exchange).
-    python tools/shard_probe.py [log2n=22] [worlds=1,2,4,8] [chain=both|replicated|partitioned]
+    python tools/shard_probe.py [log2n=22] [worlds=1,2,4,8] [chain=both|replicated|partitioned] [window_bits=0 (the plan's)]
 With the chain partitioned (ZK_FLAG_PARTITIONED_CHAIN) rank 0 runs its block's phases through zk_shard_*
 with the all_to_all left out: its exchange buffers keep whatever they hold, so the RESULT is meaningless
 but the work (kernels, sizes, launch counts) is exactly a rank's — what is missing is the four rounds of
@@ -18,12 +18,13 @@ wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mu
 w = torch.from_numpy(synth.make_witness(k, seed=0)).cuda()
 worlds = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8]
 chain = sys.argv[3] if len(sys.argv) > 3 else "both"
+wbits = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 for G in worlds:
     for mode in ("replicated", "partitioned"):
         if chain not in ("both", mode) or (mode == "partitioned" and G not in (2, 4, 8)):
             continue
         part = mode == "partitioned"
-        p = bench.ProverFromView(zk, wl, device=0, shard_index=0, shard_count=G, window_bits=0, timings=True, precomp=True, partitioned_chain=part)
+        p = bench.ProverFromView(zk, wl, device=0, shard_index=0, shard_count=G, window_bits=wbits, timings=True, precomp=True, partitioned_chain=part)
         if part:
             ch = ShardedChain(p.lib, p.h, None, torch.device("cuda:0"), exchange=lambda dst, src: None)
             submit = lambda: ch.submit(d_wtns=w.data_ptr())
