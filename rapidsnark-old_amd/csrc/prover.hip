@@ -224,7 +224,7 @@ struct zk_prover {
         hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_done = nullptr;
         hipEvent_t ev_tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t ev[20];      // 0-6 stage marks; 8/9, 13/14, 15/16, 17/18: G1 level-1 kernels of MSM A, B1, C, H; 10/11: G2; 12: upload
+        hipEvent_t ev[20] = {};  // 0-6 stage marks; 8/9, 13/14, 15/16, 17/18: G1 level-1 kernels of MSM A, B1, C, H; 10/11: G2; 12: upload
         bool have_events = false;
         uint8_t *w1 = nullptr, *w2 = nullptr;      // pinned host copies of the window sums
         size_t w1_bytes = 0, w2_bytes = 0;
@@ -256,7 +256,7 @@ struct zk_prover {
             for (auto &e : ev_l1) if (e) (void)hipEventDestroy(e);
             for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_done}) if (e) (void)hipEventDestroy(e);
             for (auto &e : ev_tail) if (e) (void)hipEventDestroy(e);
-            if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
+            for (auto &e : ev) if (e) (void)hipEventDestroy(e);
             if (w1) (void)hipHostFree(w1);
             if (w2) (void)hipHostFree(w2);
             if (wtns_pin) (void)hipHostFree(wtns_pin);
@@ -419,13 +419,17 @@ static void alloc_slot(zk_prover *p, int i) {
     }
     q.w1_bytes = (size_t)(3 * ew + eh) * sizeof(G1XYZZ);
     q.w2_bytes = (size_t)ew * sizeof(G2XYZZ);
-    HIP_TRY(hipHostMalloc((void **)&q.w1, q.w1_bytes, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&q.w2, q.w2_bytes, hipHostMallocDefault));
-    for (auto &e : q.ev_l1) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // (a call that ran out of memory half-way is repeated by the next submission: nothing below is made twice)
+    if (!q.w1) HIP_TRY(hipHostMalloc((void **)&q.w1, q.w1_bytes, hipHostMallocDefault));
+    if (!q.w2) HIP_TRY(hipHostMalloc((void **)&q.w2, q.w2_bytes, hipHostMallocDefault));
+    for (auto &e : q.ev_l1)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t *e : {&q.ev_fork, &q.ev_join, &q.ev_sortw, &q.ev_main, &q.ev_done})
-        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    for (auto &e : q.ev_tail) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : q.ev) HIP_TRY(hipEventCreate(&e));
+        if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (auto &e : q.ev_tail)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : q.ev)
+        if (!e) HIP_TRY(hipEventCreate(&e));
     q.have_events = true;
     q.allocated = true;
 }
