@@ -56,13 +56,38 @@ static ssize_t recv_some(int fd, char *buf, size_t len) {
 
 // per connection: does the client want it kept open after this response?
 static thread_local bool t_keep = false;
+// a request was refused before its body was read (413, 431, 501, 400): the client may still be sending
+static thread_local bool t_unread = false;
 
 static void respond(int fd, int code, const char *reason, const std::string &body, const char *ctype) {
-    if (code >= 400 && code != 404 && code != 503) t_keep = false;      // malformed / oversized requests end the connection
+    if (code >= 400 && code != 404 && code != 503) {      // malformed / oversized requests end the connection
+        t_keep = false;
+        t_unread = true;
+    }
     std::string h = "HTTP/1.1 " + std::to_string(code) + " " + reason + "\r\n";
     if (ctype) h += std::string("Content-Type: ") + ctype + "\r\n";
     h += "Content-Length: " + std::to_string(body.size()) + (t_keep ? "\r\nConnection: keep-alive\r\n\r\n" : "\r\nConnection: close\r\n\r\n");
     if (!send_all(fd, h + body)) t_keep = false;
+}
+
+// Closing a socket with unread data in its receive buffer sends a reset, and the reset can overtake the response the client
+// has not read yet (it is still busy sending the body that was refused).  So: send side shut down, what arrives is read and
+// dropped until the client closes or a second has passed, then the socket is closed.
+static void lingering_close(int fd) {
+    ::shutdown(fd, SHUT_WR);
+    timeval brief{0, 200000};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &brief, sizeof brief);
+    char sink[65536];
+    size_t dropped = 0;
+    for (int rounds = 0; rounds < 5 && dropped < ((size_t)8 << 20); rounds++) {
+        ssize_t k = recv_some(fd, sink, sizeof sink);
+        if (k == 0) break;
+        if (k > 0) {
+            dropped += (size_t)k;
+            rounds = 0;
+        }
+    }
+    ::close(fd);
 }
 
 static std::string lower(std::string s) {
@@ -74,6 +99,7 @@ static std::string lower(std::string s) {
 // next request before it has read the answer).  Sets t_keep; a closed / idle / broken connection clears it.
 static void handle(int fd, FullProver &fp, std::string &buf) {
     t_keep = false;
+    t_unread = false;
     size_t hdr_end = buf.find("\r\n\r\n");
     char tmp[65536];
     while (hdr_end == std::string::npos) {
@@ -228,7 +254,9 @@ int main(int argc, char **argv) {
                         keep = false;                     // idle for half a minute
                     }
                     if (!keep) {
-                        ::close(c.fd);
+                        if (t_unread) lingering_close(c.fd);
+                        else ::close(c.fd);
+                        t_unread = false;
                         conns[i] = std::move(conns.back());
                         conns.pop_back();
                         if (i + 1 < pfds.size()) pfds[i + 1] = pfds.back();
