@@ -131,6 +131,14 @@ int zk_prove_submit(zk_prover *p, const uint8_t *wtns, const uint8_t *r32, const
 int zk_host_alloc(void **out, size_t bytes);
 void zk_host_free(void *ptr);
 int zk_prove_collect(zk_prover *p, zk_proof *out);
+/* Per-proof workspace is allocated the first time a slot / lane is used (the one-shot CLI never needs more than one).  A
+ * server that will keep `in_flight` proofs in flight calls this once after create: every proof slot and lane such a
+ * pipeline walks (all ZK_MAX_IN_FLIGHT of them when in_flight >= 2, slot 0 for 1) is allocated NOW — with
+ * host_witnesses != 0 including the per-slot HBM witness buffer and its pinned staging copy — so that running out of
+ * device memory is a start-up error the caller can react to (tables as in the zkey instead of the window-precomputed
+ * ones) and never a failed proof later.  Replaces nothing in the reference (its workspace is `new FrElement[]` per proof,
+ * src/groth16.cpp:52-60). */
+int zk_prover_reserve(zk_prover *p, uint32_t in_flight, uint32_t host_witnesses);
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);
 /* Batched proving (a prover created with opts.batch = B >= 2): `count` (1..B) witnesses of the circuit, given as
  * `count` host pointers, are proved by ONE submission — one digit sort with a bucket set per witness, one set of

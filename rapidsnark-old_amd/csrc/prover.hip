@@ -222,7 +222,8 @@ struct zk_prover {
         DevBuf<G1XYZZ> wsum_g1;
         DevBuf<G2XYZZ> wsum_g2;
         hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_done = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_done = nullptr, ev_chain = nullptr;
+        bool defer_w = false;                 // lone proof: the witness MSMs are enqueued behind the transform chain (phase_local), see phase_front
         hipEvent_t ev_tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev[20] = {};  // 0-6 stage marks; 8/9, 13/14, 15/16, 17/18: G1 level-1 kernels of MSM A, B1, C, H; 10/11: G2; 12: upload
         bool have_events = false;
@@ -254,7 +255,7 @@ struct zk_prover {
             if (graph) (void)hipGraphDestroy(graph);
             if (ev_gdone) (void)hipEventDestroy(ev_gdone);
             for (auto &e : ev_l1) if (e) (void)hipEventDestroy(e);
-            for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_done}) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {ev_fork, ev_join, ev_sortw, ev_main, ev_done, ev_chain}) if (e) (void)hipEventDestroy(e);
             for (auto &e : ev_tail) if (e) (void)hipEventDestroy(e);
             for (auto &e : ev) if (e) (void)hipEventDestroy(e);
             if (w1) (void)hipHostFree(w1);
@@ -285,16 +286,20 @@ struct zk_prover {
         uint64_t n_abc = 0, n_h = 0, nh_sort = 0;
         uint32_t wbits = 0, batch = 1;
         bool precomp = false, one_stream = false;
+        bool ready = false;         // set at the END of ensure(), like ProofSlot::allocated: a call that ran out of memory half-way
+                                    // (six proofs in flight at 2^22 next to nearly full tables) is repeated by the next proof on the
+                                    // lane instead of leaving h / sort_h null behind a non-null abc
         void ensure() {
-            if (abc.p) return;
-            if (!stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            if (ready) return;
+            if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            if (!stream2) {
                 if (one_stream) stream2 = stream;
                 else HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
             }
-            abc.alloc(n_abc);
-            h.alloc(n_h);
-            sort_h.alloc(nh_sort, wbits, precomp, batch);
+            if (!abc.p) abc.alloc(n_abc);
+            if (!h.p) h.alloc(n_h);
+            sort_h.alloc(nh_sort, wbits, precomp, batch);      // (releases what an interrupted call left, then allocates all nine buffers)
+            ready = true;
         }
         ~LaneExtra() {
             if (stream2 && stream2 != stream) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
@@ -424,7 +429,7 @@ static void alloc_slot(zk_prover *p, int i) {
     if (!q.w2) HIP_TRY(hipHostMalloc((void **)&q.w2, q.w2_bytes, hipHostMallocDefault));
     for (auto &e : q.ev_l1)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t *e : {&q.ev_fork, &q.ev_join, &q.ev_sortw, &q.ev_main, &q.ev_done})
+    for (hipEvent_t *e : {&q.ev_fork, &q.ev_join, &q.ev_sortw, &q.ev_main, &q.ev_done, &q.ev_chain})
         if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (auto &e : q.ev_tail)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -742,17 +747,19 @@ static void stage_job_run(void *arg) {
     memcpy(j->dst, j->src, per < j->bytes ? per : j->bytes);
     for (auto &t : th) t.join();
 }
+// the slot's HBM witness buffer and the events of its upload (host-witness proofs)
+static void ensure_witness_buffer(zk_prover *p, zk_prover::ProofSlot &q) {
+    if (!q.wtns_dev.p) q.wtns_dev.alloc((uint64_t)p->nVars * p->batch);
+    if (!q.ev_h2d) HIP_TRY(hipEventCreateWithFlags(&q.ev_h2d, hipEventDisableTiming));
+    if (!q.ev_h2d_start) HIP_TRY(hipEventCreate(&q.ev_h2d_start));
+}
 // `count` host witnesses (count <= the prover's batch) -> consecutive nVars-element vectors of the slot's buffer; the
 // vectors of a batch that are not used are zeroed (an all-zero witness has no non-zero digit: it costs nothing in
 // the MSMs).  d_src (batch provers fed a device pointer): vector 0 is copied from device memory instead.
 static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const uint8_t *const *h_wtns, uint32_t count,
                                   hipEvent_t src_ready = nullptr, const Fr *d_src = nullptr) {
     const size_t bytes = (size_t)p->nVars * 32;
-    if (!q.wtns_dev.p) q.wtns_dev.alloc((uint64_t)p->nVars * p->batch);
-    if (!q.ev_h2d) {
-        HIP_TRY(hipEventCreateWithFlags(&q.ev_h2d, hipEventDisableTiming));
-        HIP_TRY(hipEventCreate(&q.ev_h2d_start));
-    }
+    ensure_witness_buffer(p, q);
     hipStream_t sh = p->stream_h2d;
     if (src_ready) HIP_TRY(hipStreamWaitEvent(sh, src_ready, 0));      // the (pinned) source is still being filled
     const bool tm = (p->flags & ZK_FLAG_TIMINGS) != 0;
@@ -877,6 +884,58 @@ struct BatchIn {
     const uint8_t *r32s, *s32s;
 };
 
+// ZKHIP_LONE_ORDER=0/1 (-DZK_PROBES builds): same-box A/B of the lone-proof launch order
+static bool lone_order(const zk_prover *p) {
+    static const int forced = [] { const char *e = probe_env("ZKHIP_LONE_ORDER"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    return p->shard_count == 1 && !p->part && p->logn >= 18;
+}
+
+// MSM B2, A, B1 over the shared bucket order of sort(w), on stream 2 (src/groth16.cpp:180-197)
+static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
+    zk_prover::ProofSlot &q = c.q;
+    hipStream_t s2 = c.s2;
+    const bool tails = c.ntails != 0;
+    const bool tm = c.tm;
+    // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: on their
+    // own streams they neither delay the next level-1 kernel of their MSM's stream nor pile up
+    // behind the last one
+    const uint32_t tbw = c.tbw, Ww = c.Ww;
+    const uint64_t ew = c.ew;
+    const MsmPlan pw = c.pw;
+    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
+    if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, c.tail[4]);
+    if (p->batch_abc) {
+        // small circuits: MSM A, B1 and C (same scalars, same sorted entries) in ONE set of launches —
+        // level-1 accumulation, merges and bucket reduction each cost what one MSM's cost
+        AccumBatch b;
+        memset(&b, 0, sizeof b);
+        b.n = 3;
+        b.points[0] = p->ptsA.p; b.points[1] = p->ptsB1.p; b.points[2] = p->ptsC.p;
+        b.idx_min[2] = b.idx_sub[2] = p->c_idx_min;
+        b.bucket_stride = tbw;
+        b.ws_stride = q.acc_stride;
+        launch_msm_accum_g1_batch(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, b, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
+        if (tm) for (int e : {13, 14, 15, 16}) HIP_TRY(hipEventRecord(q.ev[e], s2));      // (B1 and C have no launch of their own)
+        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 3, pw, c.after(0, s2));
+        if (!tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
+        HIP_TRY(hipEventRecord(q.ev_join, s2));
+    } else {
+    launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
+    if (tails) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, c.tail[0]);
+    launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1], q.acc_key[1], q.acc_flag[1], s2, tm ? &q.ev[13] : nullptr, c.tail_of(1));
+    if (tails) {
+        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, c.tail[1]);
+    } else {
+        // bucket reductions stay on the stream of their MSMs
+        launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
+        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 2, pw, s2);
+    }
+    HIP_TRY(hipEventRecord(q.ev_join, s2));
+    }
+
+}
+
 int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uint8_t *r32, const uint8_t *s32, hipEvent_t src_ready = nullptr,
                 const BatchIn *bi = nullptr) {
     DeviceGuard g(p->device);
@@ -938,42 +997,15 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     }
     q.sort_w.run(d_wtns + p->sv.lo, s2);
     HIP_TRY(hipEventRecord(q.ev_sortw, s2));
-    // follow-up kernels (partial merges, bucket reductions) are small and latency-bound: on their
-    // own streams they neither delay the next level-1 kernel of their MSM's stream nor pile up
-    // behind the last one
-    const uint32_t tbw = c.tbw, Ww = c.Ww;
-    const uint64_t ew = c.ew;
-    const MsmPlan pw = c.pw;
-    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
-    if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, c.tail[4]);
-    if (p->batch_abc) {
-        // small circuits: MSM A, B1 and C (same scalars, same sorted entries) in ONE set of launches —
-        // level-1 accumulation, merges and bucket reduction each cost what one MSM's cost
-        AccumBatch b;
-        memset(&b, 0, sizeof b);
-        b.n = 3;
-        b.points[0] = p->ptsA.p; b.points[1] = p->ptsB1.p; b.points[2] = p->ptsC.p;
-        b.idx_min[2] = b.idx_sub[2] = p->c_idx_min;
-        b.bucket_stride = tbw;
-        b.ws_stride = q.acc_stride;
-        launch_msm_accum_g1_batch(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, b, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
-        if (tm) for (int e : {13, 14, 15, 16}) HIP_TRY(hipEventRecord(q.ev[e], s2));      // (B1 and C have no launch of their own)
-        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 3, pw, c.after(0, s2));
-        if (!tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
-        HIP_TRY(hipEventRecord(q.ev_join, s2));
-    } else {
-    launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
-    if (tails) launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 1, pw, c.tail[0]);
-    launch_msm_accum_g1(c.bB1, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB1.p, 0, 0, tbw, ew, q.acc_ws_g1[1], q.acc_key[1], q.acc_flag[1], s2, tm ? &q.ev[13] : nullptr, c.tail_of(1));
-    if (tails) {
-        launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, c.tail[1]);
-    } else {
-        // bucket reductions stay on the stream of their MSMs
-        launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
-        launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 2, pw, s2);
-    }
-    HIP_TRY(hipEventRecord(q.ev_join, s2));
-    }
+    // A LONE proof (nothing else in flight, unsharded, large): the witness MSMs wait for the end of the transform chain.
+    // Their first launch, the G2 accumulation, is ONE round of workgroups that hold every register of the chip for its whole
+    // 11 ms: started beside the chain it starves the chain's last pass (0.9 ms of work took 16.6 ms,
+    // profiles/r04a_lone_proof_timeline_2p22.txt), so h, sort(h) and MSM H only began when MSM A was already done, and
+    // 3 ms of merges, reductions and sort(h) ended up exposed between the level-1 launches instead of beside them.
+    // Behind the chain (3.9 ms beside sort(w), which it hides) both streams have level-1 launches to alternate from
+    // then on.  With other proofs in flight their kernels fill these gaps and the order does not matter.
+    q.defer_w = lone_order(p) && !p->capturing && !p->use_graph && p->in_flight == 0 && s2 != s && !p->batch_abc;
+    if (!q.defer_w) enqueue_witness_msms(p, c);
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
     // 1-3: a = A.w, b = B.w, c = a o b   (src/groth16.cpp:52-96) — on the rows this prover holds
@@ -1035,6 +1067,12 @@ void phase_local(zk_prover *p) {
         launch_ntt_dit_forward(c.abc, nl, 3 * c.q.count, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
     }
     if (a2a) launch_chunk_pack(p->pk_use, c.abc, 3, p->logn, p->log_shards, c.s);
+    if (c.q.defer_w) {                   // lone proof: now the witness MSMs (phase_front)
+        HIP_TRY(hipEventRecord(c.q.ev_chain, c.s));
+        HIP_TRY(hipStreamWaitEvent(c.s2, c.q.ev_chain, 0));
+        enqueue_witness_msms(p, c);
+        c.q.defer_w = false;
+    }
     p->phase_next = p->part ? 3 : 4;
 }
 
@@ -1447,6 +1485,26 @@ int zk_prove_batch_collect(zk_prover *p, zk_proof *out, uint32_t count) {
         d.count = count;
         if (p->batch == 1 && count != 1) throw std::invalid_argument("this prover was not created with opts.batch");
         collect_sums(p, nullptr, nullptr, &d);
+    });
+}
+
+int zk_prover_reserve(zk_prover *p, uint32_t in_flight, uint32_t host_witnesses) {
+    return guarded([&] {
+        if (!p) throw std::invalid_argument("null argument");
+        if (in_flight > ZK_MAX_IN_FLIGHT) throw std::invalid_argument("in_flight > ZK_MAX_IN_FLIGHT");
+        std::lock_guard<std::mutex> lk(p->mtx);
+        DeviceGuard g(p->device);
+        // a pipeline walks the whole ring of slots (slot i runs on lane i % lanes); one proof at a time lives in slot 0
+        const int nslots = in_flight >= 2 ? ZK_MAX_IN_FLIGHT : 1;
+        for (int i = 0; i < nslots; i++) {
+            alloc_slot(p, i);
+            if (host_witnesses) {
+                zk_prover::ProofSlot &q = p->slot[i];
+                ensure_witness_buffer(p, q);
+                if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, (size_t)p->nVars * 32 * p->batch, hipHostMallocDefault));
+            }
+        }
+        for (int lane = 1; lane < p->lanes && lane < nslots; lane++) p->extra[lane - 1]->ensure();
     });
 }
 

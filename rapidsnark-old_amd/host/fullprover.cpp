@@ -83,6 +83,12 @@ std::vector<int> workerDevicesFromEnv() {
 
 }   // namespace
 
+// depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs GiBs of
+// workspace); small circuits are latency-bound per proof and want the maximum
+static size_t depthFor(uint32_t domainSize) {
+    return domainSize > (1u << 22) ? 3 : (domainSize >= (1u << 19) ? 6 : ZK_MAX_IN_FLIGHT);
+}
+
 FullProver::FullProver(std::string zkeyFileNames[], int size) {
     workerDevices = workerDevicesFromEnv();
     if (const char *q = getenv("ZKHIP_QUEUE")) queueCap = (size_t)strtoul(q, nullptr, 10);
@@ -102,11 +108,14 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
             const char *be = getenv("ZKHIP_BATCH");
             batch = be ? (uint32_t)strtoul(be, nullptr, 10) : (hdr->domainSize <= (1u << 17) ? 4u : 0u);
         }
+        // every slot and lane the pipeline will walk is allocated at start-up (an out-of-memory there falls back to the tables
+        // as in the zkey, or ends the start — never a proof later)
+        const uint32_t reserve = queueMode() ? (uint32_t)depthFor(hdr->domainSize) : 1u;
         for (int dev : workerDevices)
             c.replica.push_back(Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
                                                     hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
                                                     zkey->getSectionData(5), zkey->getSectionData(6), zkey->getSectionData(7),
-                                                    zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true, dev, batch));
+                                                    zkey->getSectionData(8), zkey->getSectionData(9), sizes, /*precompDefault=*/true, dev, batch, reserve));
         // libzkhip copied everything it needs to the GPU: only the scalar header fields are kept
         // (the vk pointers into the mapping die with `zkey` and are never used again here)
         hdr->vk_alpha1 = hdr->vk_beta1 = hdr->vk_beta2 = hdr->vk_gamma2 = hdr->vk_delta1 = hdr->vk_delta2 = nullptr;
@@ -288,11 +297,16 @@ bool FullProver::enqueue(std::string input, std::string circuit, uint64_t &id) {
 }
 
 bool FullProver::enqueueWitness(std::string wtnsImage, std::string circuit, uint64_t &id) {
+    {   // a place in the queue FIRST (counted like a job inside a generator): a request that is going to get a 503 costs
+        // nothing — the image is attacker-sized (up to 128 MB, millions of directory entries) and parsed on the HTTP thread
+        std::lock_guard<std::mutex> guard(mtx);
+        if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
+        inWitness++;
+    }
     JobPtr j = std::make_shared<Job>();
     j->circuit = std::move(circuit);
-    j->haveImage = true;
     std::string error;
-    try {        // parsed on the HTTP thread that received it: nothing here needs the prover's lock
+    try {        // nothing here needs the prover's lock
         auto known = circuits.find(j->circuit);
         if (known == circuits.end()) throw std::runtime_error("unknown circuit: " + j->circuit);
         j->wtns = BinFileUtils::fromMemory(std::move(wtnsImage), "wtns", 2);
@@ -301,7 +315,7 @@ bool FullProver::enqueueWitness(std::string wtnsImage, std::string circuit, uint
         error = e.what();
     }
     std::lock_guard<std::mutex> guard(mtx);
-    if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
+    inWitness--;                                 // the reserved place becomes a ready job (or is given back)
     j->id = id = nextId++;
     j->epoch = abortEpoch;
     remember(j);
@@ -430,10 +444,7 @@ void FullProver::deviceLoop(size_t worker) {
             readyJobs.pop_front();
             jobs.push_back(job);
         }
-        // depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs GiBs of
-        // workspace); small circuits are latency-bound per proof and want the maximum
-        const uint32_t ds = circuits[job->circuit].header->domainSize;
-        const size_t depth = ds > (1u << 22) ? 3 : (ds >= (1u << 19) ? 6 : ZK_MAX_IN_FLIGHT);
+        const size_t depth = depthFor(circuits[job->circuit].header->domainSize);
         {
             std::unique_lock<std::mutex> lk(wm);
             cv.wait(lk, [&] { return perCircuit[job->circuit] < depth; });

@@ -62,7 +62,6 @@ private:
         std::unique_ptr<BinFileUtils::BinFile> wtns;   // the witness image stays mapped until the proof is collected
         const uint8_t *wtnsData = nullptr;
         bool canceled = false;
-        bool haveImage = false;                        // `input` holds a .wtns image, not circom input JSON
         uint64_t epoch = 0;                            // value of abortEpoch when the job was accepted
     };
     typedef std::shared_ptr<Job> JobPtr;

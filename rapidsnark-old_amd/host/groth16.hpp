@@ -111,7 +111,7 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
                                           void *vk_alpha1, void *vk_beta1, void *vk_beta2, void *vk_delta1, void *vk_delta2,
                                           void *coefs, void *pointsA, void *pointsB1, void *pointsB2, void *pointsC,
                                           void *pointsH, const uint64_t sectionBytes[6] = nullptr, bool precompDefault = false,
-                                          int device = -1, uint32_t batch = 0) {
+                                          int device = -1, uint32_t batch = 0, uint32_t reserveInFlight = 0) {
     zk_zkey_view v{};
     v.nVars = nVars;
     v.nPublic = nPublic;
@@ -158,14 +158,26 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     }
     if (batch > 1 && (o.flags & ZK_FLAG_PRECOMP)) o.batch = batch > ZK_MAX_BATCH ? ZK_MAX_BATCH : batch;
     zk_prover *h = nullptr;
-    int rc = zk_prover_create(&h, &v, &o);
+    // reserveInFlight (proverServer): the workspace of every proof slot and lane a pipeline of that depth walks is allocated
+    // NOW (zk_prover_reserve) — slots and lanes otherwise appear when a depth is first reached, and a GPU whose tables
+    // nearly fill its memory would create successfully and fail proofs later
+    auto create = [&] {
+        int rc = zk_prover_create(&h, &v, &o);
+        if (rc == 0 && reserveInFlight && (rc = zk_prover_reserve(h, reserveInFlight, 1)) != 0) {
+            zk_prover_destroy(h);
+            h = nullptr;
+        }
+        return rc;
+    };
+    int rc = create();
     // window-precomputed tables are 13 x the table memory (2^26 constraints: > 288 GB): where they were only the DEFAULT
-    // (proverServer) and do not fit, the prover is created with the tables as they are in the zkey instead of not at all
+    // (proverServer) and they, or the proof workspace beside them, do not fit, the prover is created with the tables as they
+    // are in the zkey instead of not at all
     if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !pc && strstr(zk_last_error(), "out of memory")) {
         std::cerr << "window-precomputed tables do not fit the GPU's free memory: using the tables as in the zkey\n";
         o.flags &= ~(uint32_t)ZK_FLAG_PRECOMP;
         o.batch = 0;
-        rc = zk_prover_create(&h, &v, &o);
+        rc = create();
     }
     if (rc != 0) throw std::runtime_error(zk_last_error());
     return std::unique_ptr<Prover>(new Prover(h, o.batch));

@@ -48,6 +48,8 @@ std::optional<Scalar32> scalar_from_env(const char *name) {
 void write_text(const std::string &path, const std::string &text) {
     std::ofstream out(path);
     out << text;
+    out.close();                 // before the state is read: a full disk shows up at the flush
+    if (!out) throw std::runtime_error("could not write " + path);      // (the program leaves through _exit below: nothing later would notice)
 }
 
 std::string public_signals_json(const uint8_t *witness, uint32_t nPublic) {

@@ -50,7 +50,7 @@ ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "ms
 
 # every symbol include/zkhip.h declares (tests check the library exports all of them)
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
-           "zk_prove_dev_submit", "zk_prove_submit", "zk_prove_batch_submit", "zk_prove_batch_collect", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
+           "zk_prove_dev_submit", "zk_prove_submit", "zk_prove_batch_submit", "zk_prove_batch_collect", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prover_reserve", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_coef_accumulate", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
            "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble",
            "zk_multi_prover_create", "zk_multi_prover_destroy", "zk_multi_prove", "zk_multi_prove_submit", "zk_multi_prove_collect",
@@ -97,6 +97,7 @@ def load_library():
     lib.zk_prove_finish.argtypes = [C.c_void_p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_assemble.argtypes = [u8p, u8p, u8p, u8p, u8p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_prover_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
+    lib.zk_prover_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.zk_multi_prover_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(zk_zkey_view), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(zk_opts)]
     lib.zk_multi_prover_destroy.argtypes = [C.c_void_p]
     lib.zk_multi_prover_destroy.restype = None

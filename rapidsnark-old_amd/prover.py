@@ -170,6 +170,11 @@ class Prover:
         L.check(self._lib.zk_prove_finish(self._h, arr, len(partials), rp, sp, C.byref(out)))
         return bytes(out)
 
+    def reserve(self, in_flight, host_witnesses=True):
+        """zk_prover_reserve: allocate NOW every proof slot and lane a pipeline of `in_flight` proofs walks (a server's
+        start-up check: out of device memory is raised here, not by a proof later)."""
+        L.check(self._lib.zk_prover_reserve(self._h, in_flight, 1 if host_witnesses else 0))
+
     def timings(self):
         ms = (C.c_double * len(L.ZK_T_NAMES))()
         L.check(self._lib.zk_prover_timings(self._h, ms, len(L.ZK_T_NAMES)))

@@ -162,3 +162,12 @@ def test_damaged_files_end_in_an_error_exit_never_in_a_signal(tmp_path):
         r = run(str(zp), str(wp), str(tmp_path / "p.json"), str(tmp_path / "q.json"))
         assert r.returncode in (0, 255), (n, kind, len(blob), r.returncode, r.stderr[-300:])
         assert r.returncode == 0 or r.stderr.strip(), (n, kind, "silent failure")
+
+
+@pytest.mark.gpu
+def test_cli_reports_an_output_file_it_could_not_write(tmp_path):
+    """The program leaves through _exit once both files are written: a proof that did NOT reach the disk must not exit 0."""
+    r = run(golden_path("r1cs_n8", "circuit.zkey"), golden_path("r1cs_n8", "witness.wtns"), str(tmp_path / "no_such_dir" / "proof.json"), str(tmp_path / "q.json"))
+    assert r.returncode == 255 and "could not write" in r.stderr
+    r = run(golden_path("r1cs_n8", "circuit.zkey"), golden_path("r1cs_n8", "witness.wtns"), str(tmp_path / "p.json"), "/dev/full")
+    assert r.returncode == 255 and "could not write /dev/full" in r.stderr

@@ -28,8 +28,8 @@ def _workload(zk, k):
 
 
 def _prover(zk, wl, **kw):
-    import bench
-    return bench.ProverFromView(zk, wl, device=0, shard_index=kw.get("shard_index", 0), shard_count=kw.get("shard_count", 1),
+    from rapidsnark_old_amd import views
+    return views.ProverFromView(zk, wl, device=0, shard_index=kw.get("shard_index", 0), shard_count=kw.get("shard_count", 1),
                                 window_bits=0, timings=False, precomp=kw.get("precomp", False))
 
 
@@ -100,9 +100,9 @@ def test_2p24_sharded8_on_one_gpu(zk):
     # zk_multi_prover with eight shards and the chain PARTITIONED — blocks of 2^21 (local pass plan of a 2^21 block + three
     # cross stages, k_ntt_cross<.,3>), A.w/B.w rows split by block, peer writes and cross-device events (all on device 0
     # here), partial sums added on the host — window-precomputed tables, then tables as in the zkey
-    import bench
+    from rapidsnark_old_amd import views
     for precomp in (True, False):
-        mp = bench.MultiProverFromView(zk, wl, [0] * shards, precomp=precomp)
+        mp = views.MultiProverFromView(zk, wl, [0] * shards, precomp=precomp)
         assert mp.n_shards == shards and mp.chain_partitioned
         assert mp.prove(w, r, s) == want
         mp.close()

@@ -29,8 +29,8 @@ def _gpu_workload(zk, k):
 
 
 def _prover(zk, wl, **kw):
-    import bench
-    return bench.ProverFromView(zk, wl, device=0, shard_index=kw.get("shard_index", 0), shard_count=kw.get("shard_count", 1),
+    from rapidsnark_old_amd import views
+    return views.ProverFromView(zk, wl, device=0, shard_index=kw.get("shard_index", 0), shard_count=kw.get("shard_count", 1),
                                 window_bits=kw.get("window_bits", 0), timings=False, precomp=kw.get("precomp", False))
 
 

@@ -40,14 +40,14 @@ def test_coef_accumulate_operator_matches_oracle(zk):
 @pytest.mark.parametrize("k,npub", [(6, 1), (12, 2), (16, 3)])
 def test_generated_key_is_valid(zk, k, npub):
     from rapidsnark_old_amd import zkgen
-    import bench
+    from rapidsnark_old_amd import views
     key = zkgen.generate(k, npub, seed=7)
     assert key["nVars"] == 1 << k and key["pointsC"].size == (key["nVars"] - npub - 1) * 64
     r, s = 0x13579BDF, (1 << 247) - 99
     a, b, c = zkgen.expected_proof_dlogs(key, r, s)
     want = zk.g1_mul(G1B, a) + zk.g2_mul(G2B, b) + zk.g1_mul(G1B, c)
     for precomp in (False, True):
-        p = bench.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=precomp)
+        p = views.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=precomp)
         assert p.prove_host(key["witness"], r, s) == want
         p.lib.zk_prover_destroy(p.h)
     # the independent CPU restatement proves the same key to the same bytes
@@ -55,7 +55,7 @@ def test_generated_key_is_valid(zk, k, npub):
     # a witness that does not satisfy the circuit does NOT pass the trapdoor identity
     bad = key["witness"].copy()
     bad[32 * (key["nVars"] - 1)] ^= 1
-    p = bench.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False)
+    p = views.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False)
     assert p.prove_host(bad, r, s) != want
     p.lib.zk_prover_destroy(p.h)
     vk = zkgen.verification_key(key)

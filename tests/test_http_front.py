@@ -1,0 +1,130 @@
+"""The REST front end's socket behaviour without a GPU: rapidsnark-old_amd/host/http_front.hpp behind a trivial handler
+(tools/http_front_echo.cpp).  What the reference gets from Pistache (src/main_proofserver.cpp:29-41) — plus what one
+worker thread multiplexing many connections must guarantee: no client can stall another."""
+import http.client
+import os
+import socket
+import subprocess
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tools", "http_front_echo")
+
+
+@pytest.fixture(scope="module")
+def server():
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "rapidsnark-old_amd", "host"),
+                           os.path.join(ROOT, "tools", "http_front_echo.cpp"), "-o", EXE])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = subprocess.Popen([EXE, str(port), "1", "1000000"], stderr=subprocess.PIPE)      # ONE worker: every connection shares it
+    assert p.stderr.readline().strip() == b"ready"
+    yield port
+    p.kill()
+    p.wait()
+
+
+def status(port, timeout=5):
+    c = http.client.HTTPConnection("127.0.0.1", port, timeout=timeout)
+    t0 = time.perf_counter()
+    c.request("GET", "/status")
+    r = c.getresponse()
+    body = r.read()
+    c.close()
+    return r.status, body, time.perf_counter() - t0
+
+
+def test_keep_alive_pipelining_and_close(server):
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    # two requests in one segment, the second asks for close
+    s.sendall(b"GET /status HTTP/1.1\r\nHost: x\r\n\r\nPOST /echo HTTP/1.1\r\nContent-Length: 5\r\nConnection: close\r\n\r\nhello")
+    data = b""
+    while True:
+        k = s.recv(65536)
+        if not k:
+            break
+        data += k
+    assert data.count(b"HTTP/1.1 200 OK") == 2
+    assert b"Connection: keep-alive" in data and data.rstrip().endswith(b"5") and b"Connection: close" in data
+
+
+def test_a_trickling_upload_does_not_stall_the_worker(server):
+    """One worker thread; a client that sends its header and then one body byte every 0.3 s must not delay /status."""
+    slow = socket.create_connection(("127.0.0.1", server), timeout=5)
+    slow.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 8\r\n\r\n")
+    lat = []
+    for i in range(6):
+        slow.sendall(b"x")
+        code, body, dt = status(server)
+        assert code == 200 and body == b'{"status":"ok"}'
+        lat.append(dt)
+        time.sleep(0.3)
+    slow.sendall(b"xx")
+    resp = slow.recv(65536)
+    assert resp.startswith(b"HTTP/1.1 200 OK") and resp.endswith(b"8")
+    assert max(lat) < 0.25, lat          # the blocking front end answered these only after the slow client's 5 s receive timeout
+
+
+def test_a_client_that_stops_mid_header_does_not_stall_the_worker(server):
+    half = socket.create_connection(("127.0.0.1", server), timeout=5)
+    half.sendall(b"GET /status HTTP/1.1\r\nHo")
+    for _ in range(3):
+        code, _, dt = status(server)
+        assert code == 200 and dt < 0.25
+    half.close()
+
+
+def test_refusals_close_the_connection_and_the_answer_arrives(server):
+    # too large: refused from the header, while the client is still sending the body
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    s.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 2000000\r\n\r\n" + b"y" * 300000)
+    data = s.recv(65536)
+    assert data.startswith(b"HTTP/1.1 413 ") and b"Connection: close" in data
+    s.close()
+    # chunked bodies are not framed: 501, closed
+    c = http.client.HTTPConnection("127.0.0.1", server, timeout=5)
+    c.request("POST", "/echo", body=iter([b"ab", b"cd"]), headers={"Transfer-Encoding": "chunked"})
+    r = c.getresponse()
+    assert r.status == 501 and r.getheader("Connection") == "close"
+    # header block without an end
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    s.sendall(b"GET /status HTTP/1.1\r\n" + b"X-Pad: " + b"a" * 70000)
+    assert s.recv(65536).startswith(b"HTTP/1.1 431 ")
+    s.close()
+    # malformed request line
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    s.sendall(b"NONSENSE\r\n\r\n")
+    assert s.recv(65536).startswith(b"HTTP/1.1 400 ")
+    s.close()
+    # a handler that throws: 500 for that request, the server goes on
+    c = http.client.HTTPConnection("127.0.0.1", server, timeout=5)
+    c.request("POST", "/throw", body=b"")
+    r = c.getresponse()
+    assert r.status == 500 and r.read() == b"handler failed"
+    assert status(server)[0] == 200
+
+
+def test_expect_continue_and_large_body(server):
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    s.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 900000\r\nExpect: 100-continue\r\n\r\n")
+    assert s.recv(65536).startswith(b"HTTP/1.1 100 Continue")
+    s.sendall(b"z" * 900000)
+    data = b""
+    while b"900000" not in data.split(b"\r\n\r\n", 1)[-1] if b"\r\n\r\n" in data else True:
+        k = s.recv(65536)
+        assert k
+        data += k
+    assert data.startswith(b"HTTP/1.1 200 OK") and b"Connection: keep-alive" in data
+    s.close()
+
+
+def test_many_idle_connections_cost_nothing(server):
+    idle = [socket.create_connection(("127.0.0.1", server), timeout=5) for _ in range(200)]
+    code, _, dt = status(server)
+    assert code == 200 and dt < 0.25
+    for s in idle:
+        s.close()
