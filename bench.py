@@ -100,7 +100,7 @@ def main():
                                                    "latency_ms_one_at_a_time", "stage_ms") if kk in o2}
         r2 = o2["roofline"]
         out["also_2p20"]["roofline"] = {kk: r2[kk] for kk in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms", "algorithmic_bytes",
-                                                              "launch_ms_one_proof_in_flight", "frac_one_proof_in_flight", "whole_proof")}
+                                                              "launch_ms_one_proof_in_flight", "frac_one_proof_in_flight", "issue_bound", "whole_proof")}
     print(json.dumps(out), flush=True)
 
 
@@ -321,8 +321,12 @@ def run(args):
         return dt, {kk: v / nsub for kk, v in stage.items()}
 
     headline_hbm = args.witness_in == "hbm"
-    elapsed, stage = timed_run(headline_hbm, args.steps, args.warmup)
+    from rapidsnark_old_amd.telemetry import ClockSampler
+    leg_marker(zk, torch, "2p%d_headline" % args.log2n)
+    with ClockSampler(local_rank) as clock:          # shader clock + socket power WHILE the headline runs (issue-bound roofline)
+        elapsed, stage = timed_run(headline_hbm, args.steps, args.warmup)
     # the other witness placement, same K (outside the headline's timed region)
+    leg_marker(zk, torch, "2p%d_other_witness_placement" % args.log2n)
     other_elapsed, other_stage = timed_run(not headline_hbm, args.steps, 1)
 
     def one_proof(i):
@@ -356,16 +360,19 @@ def run(args):
     lone = {}
     if world == 1:                        # outside the timed region: strictly one proof at a time
         torch.cuda.synchronize()
+        leg_marker(zk, torch, "2p%d_lone_resident" % args.log2n)
         t1 = time.perf_counter()
         for i in range(3):
             one_proof(i)
             for kk, v in prover.timings().items():
                 lone[kk] = lone.get(kk, 0.0) + v / 3
         latency_ms = (time.perf_counter() - t1) / 3 * 1e3
+        leg_marker(zk, torch, "2p%d_lone_host_witness" % args.log2n)
         t1 = time.perf_counter()
         for i in range(3):
             prover.prove_host(wits_host[i % len(wits_host)])        # zk_prove: host witness, synchronous (main_prover.cpp:75)
         latency_host_ms = (time.perf_counter() - t1) / 3 * 1e3
+    leg_marker(zk, torch, "2p%d_after" % args.log2n)
     if dist:
         dist.barrier()
     if rank != 0:
@@ -395,7 +402,9 @@ def run(args):
     achieved = alg_bytes / (g1_ms * 1e-3) / 1e9
     traffic, traffic_src = traffic_from_profiles(args, config, world, "g1")
     traffic2, _ = traffic_from_profiles(args, config, world, "g2")
-    roofline = {"bound": "hbm", "kernel": "k_msm_accum_l1<Fq> (G1 bucket accumulation; 4 launches per proof: MSM A, B1, C, H — the dominant kernel by total time)",
+    issue = issue_bound_from_profiles(config, world, torch.cuda.get_device_properties(local_rank).multi_processor_count, clock.summary(), ms_per_step)
+    roofline = {"bound": "hbm", "kernel": "k_msm_accum_l1<Fq> (G1 bucket accumulation; 4 launches per proof: MSM A, B1, C, H — the dominant kernel by VALU "
+                                          "instructions (46 % of a proof's) and by exclusive time (4 launches of ~3.8 ms alone out of a ~33 ms period))",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launch_ms": round(g1_ms, 4), "launches_per_proof": 4, "algorithmic_bytes": alg_bytes,
@@ -408,6 +417,7 @@ def run(args):
                          "launch_ms": round(g2_ms, 4), "algorithmic_bytes": G2_MSM_BYTES_PER_POINT * pts_per_launch,
                          "achieved": round(G2_MSM_BYTES_PER_POINT * pts_per_launch / (g2_ms * 1e-3) / 1e9, 3),
                          "frac": round(G2_MSM_BYTES_PER_POINT * pts_per_launch / (g2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic2},
+                "issue_bound": issue,
                 "whole_proof": {"algorithmic_bytes": 1424 * n, "achieved": round(1424 * n / (ms_per_step * 1e-3) / 1e9, 2),
                                 "frac": round(1424 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                                 "note": "B_alg = 1424*n bytes per proof (SURVEY §8d) over the measured period"}}
@@ -514,6 +524,61 @@ def traffic_from_profiles(args, config, world, which):
         except (OSError, ValueError, KeyError):
             continue
     return None, "no counter pass committed for this configuration"
+
+
+def issue_bound_from_profiles(config, world, cus, clock, ms_per_step):
+    """The path's OWN roofline: it is bound by VALU issue, not by HBM.  One wave-level VALU instruction
+    of this path occupies its SIMD for ~4 cycles (v_mad_i64_i32 / 64-bit integer rate, profiles/r01_ubench_valu.txt), so
+        bound_ms = instructions per proof x 4 cycles / (SIMDs x shader clock).
+    Instructions per proof are NOT measured by this run (SQ_INSTS_VALU needs rocprofv3 --pmc around the process): like
+    `traffic` they are REPLAYED from the committed counter pass of this exact configuration
+    (profiles/*_valu_instruction_budget.json, written by tools/profile_bench.sh); the clock is sampled live while the
+    headline's timed region runs (rapidsnark_old_amd.telemetry)."""
+    import glob
+    keys = ("log2n", "parallelism", "window_bits", "precomputed_window_tables")
+    instr = src = per_kernel = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_instruction_budget.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            bc = d.get("bench_config", {})
+            if all(bc.get(kk) == config.get(kk) for kk in keys) and d.get("n_gpus") == world:
+                instr, per_kernel = d["valu_instructions_per_proof"], d.get("kernels")
+                src = "replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU pass of this command)" % os.path.relpath(path, ROOT)
+                break
+        except (OSError, ValueError, KeyError):
+            continue
+    simds = cus * 4
+    ghz = clock.get("clock_ghz")
+    out = {"valu_instructions_per_proof": instr, "instructions_source": src or "no SQ_INSTS_VALU pass committed for this configuration",
+           "cycles_per_instruction": 4.0, "simds": simds, "clock_ghz": ghz, "power_w": clock.get("power_w"), "clock_source": clock.get("source"),
+           "clock_samples": clock.get("samples"), "bound_ms": None, "achieved_frac": None,
+           "note": "bound_ms = valu_instructions_per_proof x cycles_per_instruction / (simds x clock_ghz); achieved_frac = bound_ms / ms_per_step "
+                   "(1.0 = every SIMD issues a VALU instruction of this path every 4 cycles for the whole period)"}
+    if instr and ghz:
+        out["bound_ms"] = round(instr * 4.0 / (simds * ghz * 1e9) * 1e3, 3)
+        out["achieved_frac"] = round(out["bound_ms"] / ms_per_step, 4)
+    if per_kernel:
+        out["largest_kernels"] = per_kernel
+    return out
+
+
+_LEGS = []
+
+
+def leg_marker(zk, torch, name):
+    """ZK_BENCH_LEG_MARKERS=1 (tools/profile_bench.sh): a recognisable launch between the legs of a run — zk_fr_mul_vec over
+    256 x (16 + leg) elements = a k_mul_vec<Fr> grid of 16 + leg workgroups, which the kernel trace records — so that a
+    rocprofv3 --kernel-trace of the DRIVER'S OWN COMMAND can be cut into one kernel table per leg (tools/leg_stats.py).
+    Off (no launch, no synchronisation) in a normal run."""
+    if os.environ.get("ZK_BENCH_LEG_MARKERS") != "1":
+        return
+    torch.cuda.synchronize()
+    _LEGS.append(name)
+    n = 256 * (16 + len(_LEGS))
+    a = np.zeros(32 * n, dtype=np.uint8)
+    zk.fr_mul_vec(a, a)
+    torch.cuda.synchronize()
+    sys.stderr.write("[bench] leg marker %d (grid of %d workgroups): %s\n" % (len(_LEGS), 16 + len(_LEGS), name))
 
 
 def plan_window_bits(n, world, precomp):

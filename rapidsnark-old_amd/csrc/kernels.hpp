@@ -58,12 +58,15 @@ struct NttPair {
     NttPair(const NttPair &) = delete;
     NttPair &operator=(const NttPair &) = delete;
     ~NttPair() { release(); }
-    void build(uint32_t logn_global, uint32_t logn_local, uint32_t block_index, hipStream_t s);
+    // plain: the tables of the stand-alone transforms (launch_ntt_plain) instead of the coset-evaluation pair's
+    void build(uint32_t logn_global, uint32_t logn_local, uint32_t block_index, hipStream_t s, bool plain = false);
     void release();
 };
 bool ntt_pair_supported(uint32_t local_logn);
 // in place on `batch` vectors of 2^L elements, `stride_elems` apart: natural order in, natural order out
 void launch_ntt_coset_pair(Fr *data, uint64_t stride_elems, uint32_t batch, const NttPair &t, hipStream_t s);
+// one inverse (1/n included) or forward transform per vector on the same passes; `t` built with plain = true
+void launch_ntt_plain(Fr *data, uint64_t stride_elems, uint32_t batch, const NttPair &t, bool inverse, hipStream_t s);
 
 // fill the tables (device memory already allocated: n/2, n/2, n, 1 elements)
 void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s);
@@ -153,6 +156,7 @@ uint64_t msm_accum_workspace_slots(uint64_t max_entries);
 struct AccumTail {
     hipStream_t stream = nullptr;
     hipEvent_t l1_done = nullptr;
+    bool buckets_zeroed = false;      // the caller has already cleared the bucket array (ordered before this launch)
 };
 // Up to three G1 MSMs over the SAME sorted entry list in one set of launches (blockIdx.y): MSM m uses
 // points[m], writes buckets + m*bucket_stride and the workspaces + m*ws_stride.

@@ -1255,7 +1255,7 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
                          ACCMEM *ws_part, uint32_t *ws_key, uint32_t *ws_flag, hipStream_t s, hipEvent_t *ev, AccumTail tail) {
     const uint32_t nb = batch.n ? batch.n : 1;
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
-    ZK_HIP(hipMemsetAsync(buckets, 0, ((size_t)(nb - 1) * batch.bucket_stride + total_buckets) * sizeof(ACCMEM), s));
+    if (!tail.buckets_zeroed) ZK_HIP(hipMemsetAsync(buckets, 0, ((size_t)(nb - 1) * batch.bucket_stride + total_buckets) * sizeof(ACCMEM), s));
     uint64_t lanes = accum_lanes_for<F>(max_entries, nb);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {

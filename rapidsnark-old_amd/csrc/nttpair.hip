@@ -65,6 +65,7 @@ __device__ __forceinline__ Fr29 pload_tw(const TwEntry *e) {
 __device__ __forceinline__ uint32_t v_of(uint32_t T, uint32_t k, uint32_t wlo) {
     return (T & ((1u << wlo) - 1u)) | (k << wlo) | ((T >> wlo) << (wlo + 3u));
 }
+__device__ __forceinline__ uint32_t pbrev_bits(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 // LDS: nine limb planes of 8*NT words, element v at word v ^ (v[5..7] << 2): with this XOR every window layout from
 // bit 2 up is bank-conflict free (32 lanes of a pass differ in v bits {0..wlo-1} and {wlo+3..7}: all of them reach distinct
 // bank bits), and so is the bottom window (wlo = 0), whose eight elements per thread are contiguous and move as two
@@ -260,7 +261,7 @@ __device__ __forceinline__ void run_plan(Fr29 (&x)[8], int32_t *lds, uint32_t T,
 }
 
 struct PairDev {
-    uint32_t m;                  // tile bits
+    uint32_t m, tbits;           // tile bits, strided bits (L - m)
     uint32_t batch, tiles;       // vectors per launch, workgroups per vector
     uint64_t nloc;               // elements per vector
     const TwEntry *rfwd, *rinv;  // w_4096^k, w_4096^-k, k < 2048
@@ -270,6 +271,13 @@ struct PairDev {
 };
 
 // ---------------------------------------------------------------- the middle kernel: * Tinv', DIF, * D, DIT, * T on contiguous tiles
+// MODE 0: the proof's pair, as described above.  MODE 1 / 2: ONE transform in natural order on both sides (the stand-alone
+// operator zk_fr_ntt, the counterpart of FFT::ifft / FFT::fft, src/groth16.cpp:102,115): 1 = the inverse's last pass — * Tinv
+// (1/n inside), DIF, and the results STORED at their natural positions; 2 = the forward's first pass — elements GATHERED
+// from their natural positions, DIT, * T.  Position p = tile << m | p0 of the bit-reversed order holds index
+// brev_m(p0) << t | brev_t(tile): the permutation costs no pass, only the coalescing of one side of this kernel (32-byte
+// accesses 2^t elements apart).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_elems, PairDev t) {
     extern __shared__ int32_t lds[];
     typedef Fr29 F;
@@ -289,14 +297,21 @@ __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_el
     const uint32_t T = threadIdx.x;
     const uint64_t wg_base = (uint64_t)tile << 11;
     const uint32_t wtop = t.plan.wlo[t.plan.nph - 1];            // DIF starts (and DIT ends) in the top window: coalesced
+    const uint32_t wfirst = MODE == 2 ? t.plan.wlo[0] : wtop;
     F x[8];
-    const bool active = wg_base + v_of(T, 0, wtop) < t.nloc;     // nloc < 2^11: the tail of the only workgroup idles (but meets the barriers)
+    // nloc < 2^11: the tail of the only workgroup idles (but meets the barriers); the eight elements of a thread differ in
+    // bits below m, so they are active together
+    const bool active = wg_base + v_of(T, 0, wfirst) < t.nloc && wg_base + v_of(T, 7, wfirst) < t.nloc;
+    auto natural = [&](uint32_t v) -> uint64_t {                 // natural index of the element at tile position v (MODE 1, 2)
+        return ((uint64_t)pbrev_bits(v & ((1u << t.m) - 1u), t.m) << t.tbits) | pbrev_bits(tile, t.tbits);
+    };
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const uint64_t pos = wg_base + v_of(T, k, wtop);
+        const uint32_t v = v_of(T, k, wfirst);
+        const uint64_t pos = MODE == 2 ? natural(v) : wg_base + v;
         x[k] = active ? F::load(pload_el(xg + pos)) : F::zero();
     }
-    if (t.tinv) {
+    if (MODE != 2 && t.tinv) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
             const uint64_t p0 = wg_base + v_of(T, k, wtop), p1 = wg_base + v_of(T, k + 1, wtop);
@@ -304,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_el
             F::mul2(x[k], x[k], a, x[k + 1], x[k + 1], b);
         }
     }
-    uint32_t wcur = wtop;
-    run_plan<true, 256>(x, lds, T, t.plan, 0, t.rinv, wcur);
-    {   // coset shift inside the tile (and kappa when there is no Tinv'): position p0 of the tile
+    uint32_t wcur = wfirst;
+    if (MODE != 2) run_plan<true, 256>(x, lds, T, t.plan, 0, t.rinv, wcur);
+    if (MODE == 0 || (MODE == 1 && !t.tinv)) {   // coset shift inside the tile (and kappa when there is no Tinv'): position p0 of the tile
         const uint32_t tmask = (1u << t.m) - 1u;
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
@@ -315,8 +330,8 @@ __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_el
             F::mul2(x[k], x[k], a, x[k + 1], x[k + 1], b);
         }
     }
-    run_plan<false, 256>(x, lds, T, t.plan, 0, t.rfwd, wcur);
-    if (t.tfwd) {
+    if (MODE != 1) run_plan<false, 256>(x, lds, T, t.plan, 0, t.rfwd, wcur);
+    if (MODE != 1 && t.tfwd) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
             const uint64_t p0 = wg_base + v_of(T, k, wcur), p1 = wg_base + v_of(T, k + 1, wcur);
@@ -326,7 +341,10 @@ __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_el
     }
     if (active) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) pstore_el(xg + wg_base + v_of(T, k, wcur), F::store(x[k]));
+        for (int k = 0; k < 8; k++) {
+            const uint32_t v = v_of(T, k, wcur);
+            pstore_el(xg + (MODE == 1 ? natural(v) : wg_base + v), F::store(x[k]));
+        }
     }
 }
 
@@ -405,8 +423,9 @@ __device__ __forceinline__ void pstore_tw(TwEntry *e, const Fr29 &v) {
 
 // L = bits of the local transform, Lg = bits of the whole domain (L < Lg: one block of a partitioned chain, rho = brev of
 // the block index), m / t = tile / strided bits, ta = low group of the strided bits when they are split (else t)
+// plain: tables of the stand-alone transforms (no coset shift: Tinv = w_n^(-i0 brev(p1)) / n, D = 1 — or 1/n when there is no Tinv)
 __global__ __launch_bounds__(256) void k_pair_tables(TwEntry *rfwd, TwEntry *rinv, Fr *tinv, Fr *tfwd, Fr *dtab, Fr *t2inv, Fr *t2fwd,
-                                                     uint32_t L, uint32_t Lg, uint32_t rho, uint32_t m, uint32_t ta) {
+                                                     uint32_t L, uint32_t Lg, uint32_t rho, uint32_t m, uint32_t ta, uint32_t plain) {
     const uint32_t t = L - m;
     __shared__ Fr s_w12, s_w12i, s_wn, s_wni, s_w2n, s_kappa, s_w2m, s_wt, s_wti;
     if (threadIdx.x == 0) {
@@ -433,7 +452,7 @@ __global__ __launch_bounds__(256) void k_pair_tables(TwEntry *rfwd, TwEntry *rin
             pstore_tw(rinv + i, Fr29::canonical(Fr29::from_mont256(pfr_pow(s_w12i, i))));
         }
         if (i < N1) {
-            Fr d = pfr_pow(s_w2m, pbrev((uint32_t)i, m));
+            Fr d = plain ? Fr::one() : pfr_pow(s_w2m, pbrev((uint32_t)i, m));
             if (t == 0) d = Fr::mul(d, s_kappa);
             pstore_el(dtab + i, Fr29::store(Fr29::from_mont256(d)));
         }
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(256) void k_pair_tables(TwEntry *rfwd, TwEntry *rin
             const uint64_t i0 = i & (N1 - 1), k1 = pbrev((uint32_t)(i >> m), t);
             const uint64_t e = (i0 * k1) & (n - 1);
             pstore_el(tfwd + i, Fr29::store(Fr29::from_mont256(pfr_pow(s_wn, e))));
-            pstore_el(tinv + i, Fr29::store(Fr29::from_mont256(Fr::mul(Fr::mul(pfr_pow(s_wni, e), pfr_pow(s_w2n, k1)), s_kappa))));
+            pstore_el(tinv + i, Fr29::store(Fr29::from_mont256(Fr::mul(plain ? pfr_pow(s_wni, e) : Fr::mul(pfr_pow(s_wni, e), pfr_pow(s_w2n, k1)), s_kappa))));
         }
         if (t2fwd && i < (1ull << t)) {
             const uint32_t tb = t - ta;
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256) void k_pair_tables(TwEntry *rfwd, TwEntry *rin
 // ---------------------------------------------------------------- host
 bool ntt_pair_supported(uint32_t local_logn) { return local_logn >= 3 && local_logn <= 27; }
 
-void NttPair::build(uint32_t logn_global, uint32_t logn_local, uint32_t block_index, hipStream_t s) {
+void NttPair::build(uint32_t logn_global, uint32_t logn_local, uint32_t block_index, hipStream_t s, bool plain) {
     L = logn_local;
     Lg = logn_global;
     m = L < 11 ? L : 11;
@@ -487,7 +506,7 @@ void NttPair::build(uint32_t logn_global, uint32_t logn_local, uint32_t block_in
     for (uint32_t i = 0; i < lg; i++) rho |= ((block_index >> i) & 1u) << (lg - 1 - i);
     uint64_t grid = ((n > 2048 ? n : 2048) + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_pair_tables, dim3((uint32_t)grid), dim3(256), 0, s, rfwd, rinv, tinv, tfwd, dtab, t2inv, t2fwd, L, Lg, rho, m, g[0]);
+    hipLaunchKernelGGL(k_pair_tables, dim3((uint32_t)grid), dim3(256), 0, s, rfwd, rinv, tinv, tfwd, dtab, t2inv, t2fwd, L, Lg, rho, m, g[0], plain ? 1u : 0u);
     ZK_LAUNCH_OK("ntt pair tables");
 }
 void NttPair::release() {
@@ -505,7 +524,9 @@ static void lds_opt_in() {
     ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_outer<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_ntt_mid<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr.done();
 }
 
@@ -535,39 +556,65 @@ static void run_outer(Fr *data, uint64_t stride, uint32_t batch, const NttPair &
     ZK_LAUNCH_OK("ntt outer pass");
 }
 
+template <int MODE>
+static void run_mid(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, hipStream_t s) {
+    const uint32_t t = tb.L - tb.m;
+    lds_opt_in();
+    PairDev d;
+    memset(&d, 0, sizeof d);
+    d.m = tb.m;
+    d.tbits = t;
+    d.batch = batch;
+    d.nloc = 1ull << tb.L;
+    d.rfwd = tb.rfwd;
+    d.rinv = tb.rinv;
+    d.tinv = t ? tb.tinv : nullptr;
+    d.tfwd = t ? tb.tfwd : nullptr;
+    d.dtab = tb.dtab;
+    d.plan = plan_windows(0, tb.m, 11);
+    const uint32_t wgs = (uint32_t)(((1ull << tb.L) + 2047) >> 11);
+    d.tiles = wgs;
+    const size_t shmem = (size_t)9 * 2048 * 4;
+    hipLaunchKernelGGL(k_ntt_mid<MODE>, dim3(wgs * batch), dim3(256), shmem, s, data, stride, d);
+    ZK_LAUNCH_OK("ntt middle pass");
+}
+template <bool DIF>
+static void run_outer_passes(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, hipStream_t s) {
+    const uint32_t t = tb.L - tb.m;
+    if (DIF) {
+        if (tb.ngroups == 2) {
+            run_outer<true>(data, stride, batch, tb, tb.m + tb.g[0], tb.g[1], nullptr, 0, s);
+            run_outer<true>(data, stride, batch, tb, tb.m, tb.g[0], tb.t2inv, t, s);
+        } else if (tb.ngroups == 1) {
+            run_outer<true>(data, stride, batch, tb, tb.m, t, nullptr, 0, s);
+        }
+    } else {
+        if (tb.ngroups == 2) {
+            run_outer<false>(data, stride, batch, tb, tb.m, tb.g[0], tb.t2fwd, t, s);
+            run_outer<false>(data, stride, batch, tb, tb.m + tb.g[0], tb.g[1], nullptr, 0, s);
+        } else if (tb.ngroups == 1) {
+            run_outer<false>(data, stride, batch, tb, tb.m, t, nullptr, 0, s);
+        }
+    }
+}
+
 // a | b | c (batch vectors `stride` elements apart, nloc = 2^L elements each): in place, natural order in and out
 void launch_ntt_coset_pair(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, hipStream_t s) {
-    const uint32_t t = tb.L - tb.m;
-    if (tb.ngroups == 2) {
-        run_outer<true>(data, stride, batch, tb, tb.m + tb.g[0], tb.g[1], nullptr, 0, s);
-        run_outer<true>(data, stride, batch, tb, tb.m, tb.g[0], tb.t2inv, t, s);
-    } else if (tb.ngroups == 1) {
-        run_outer<true>(data, stride, batch, tb, tb.m, t, nullptr, 0, s);
-    }
-    {
-        lds_opt_in();
-        PairDev d;
-        memset(&d, 0, sizeof d);
-        d.m = tb.m;
-        d.batch = batch;
-        d.nloc = 1ull << tb.L;
-        d.rfwd = tb.rfwd;
-        d.rinv = tb.rinv;
-        d.tinv = t ? tb.tinv : nullptr;
-        d.tfwd = t ? tb.tfwd : nullptr;
-        d.dtab = tb.dtab;
-        d.plan = plan_windows(0, tb.m, 11);
-        const uint32_t wgs = (uint32_t)(((1ull << tb.L) + 2047) >> 11);
-        d.tiles = wgs;
-        const size_t shmem = (size_t)9 * 2048 * 4;
-        hipLaunchKernelGGL(k_ntt_mid, dim3(wgs * batch), dim3(256), shmem, s, data, stride, d);
-        ZK_LAUNCH_OK("ntt middle pass");
-    }
-    if (tb.ngroups == 2) {
-        run_outer<false>(data, stride, batch, tb, tb.m, tb.g[0], tb.t2fwd, t, s);
-        run_outer<false>(data, stride, batch, tb, tb.m + tb.g[0], tb.g[1], nullptr, 0, s);
-    } else if (tb.ngroups == 1) {
-        run_outer<false>(data, stride, batch, tb, tb.m, t, nullptr, 0, s);
+    run_outer_passes<true>(data, stride, batch, tb, s);
+    run_mid<0>(data, stride, batch, tb, s);
+    run_outer_passes<false>(data, stride, batch, tb, s);
+}
+
+// ONE transform per vector, natural order in and out, on the same passes (tables built with plain = true): the inverse
+// (1/n included) is the outer DIF passes + the middle pass storing at natural positions, the forward the middle pass
+// gathering from natural positions + the outer DIT passes.  No permutation pass, no per-call table build.
+void launch_ntt_plain(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, bool inverse, hipStream_t s) {
+    if (inverse) {
+        run_outer_passes<true>(data, stride, batch, tb, s);
+        run_mid<1>(data, stride, batch, tb, s);
+    } else {
+        run_mid<2>(data, stride, batch, tb, s);
+        run_outer_passes<false>(data, stride, batch, tb, s);
     }
 }
 

@@ -14,6 +14,7 @@
 #include <sys/random.h>
 #include <string>
 #include <vector>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <memory>
@@ -223,6 +224,7 @@ struct zk_prover {
         DevBuf<G2XYZZ> wsum_g2;
         hipEvent_t ev_l1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sortw = nullptr, ev_main = nullptr, ev_done = nullptr, ev_chain = nullptr;
+        bool zeroed = false;                  // this proof's bucket arrays were cleared at submit, beside the witness upload (phase_front)
         bool defer_w = false;                 // lone proof: the witness MSMs are enqueued behind the transform chain (phase_local), see phase_front
         hipEvent_t ev_tail[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t ev[20] = {};  // 0-6 stage marks; 8/9, 13/14, 15/16, 17/18: G1 level-1 kernels of MSM A, B1, C, H; 10/11: G2; 12: upload
@@ -872,7 +874,7 @@ struct PhaseCtx {
         bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
     }
     void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
-    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; return t; }
+    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; t.buckets_zeroed = q.zeroed; return t; }
     hipStream_t after(int m, hipStream_t own) const { return tail[m] ? tail[m] : own; }
     NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
 };
@@ -987,6 +989,16 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     // stream2 depends on stream 1 only through a staged witness: with a caller-owned device witness
     // it runs ahead, so that proof k+1's witness MSMs follow proof k's directly instead of waiting
     // for proof k's stream-1 work (at 2^20 that wait left stream2 idle for a third of the period)
+    // The five bucket arrays are cleared HERE, in front of the wait for the witness: the 0.4 GiB of memsets run while the
+    // upload is still on its way (2.4 ms of PCIe time in which a lone proof has nothing else to do) instead of in front of
+    // every level-1 launch (where they showed up as 0.5-0.6 ms each beside another proof-filling kernel,
+    // profiles/r04b_lone_proof_timeline_2p22.txt).  The slot's previous proof has been collected: nothing reads them.
+    q.zeroed = !p->capturing && !p->use_graph;
+    if (q.zeroed) {
+        HIP_TRY(hipMemsetAsync(c.bA, 0, (size_t)3 * c.tbw * sizeof(G1Acc), s2));        // A | B1 | C (C's launch on stream 1 waits for sort(w) on stream 2)
+        HIP_TRY(hipMemsetAsync(q.buckets_g2.p, 0, (size_t)c.tbw * sizeof(G2Acc), s2));
+        HIP_TRY(hipMemsetAsync(c.bH, 0, (size_t)c.tbh * sizeof(G1Acc), s));
+    }
     if (staged) {
         HIP_TRY(hipStreamWaitEvent(s, q.ev_h2d, 0));
         HIP_TRY(hipStreamWaitEvent(s2, q.ev_h2d, 0));
@@ -1887,17 +1899,39 @@ int zk_fr_coef_accumulate(uint8_t *a, uint8_t *b, const void *coefs, uint64_t nC
     });
 }
 
+// Tables of the stand-alone transforms, kept per device for the size used last (2 n field elements: a caller that
+// transforms many vectors of one size — zkgen, the KATs — builds them once).
+static std::mutex g_plain_mtx;
+static std::map<int, std::unique_ptr<NttPair>> &g_plain_tables = *new std::map<int, std::unique_ptr<NttPair>>();      // (never destroyed: no hipFree behind the runtime's own exit handlers)
+
 int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse) {
     return guarded([&] {
         need_device();
         uint32_t logn = ilog2_exact(n);
         if (logn > 28) throw std::invalid_argument("n exceeds 2^28");
-        Tables tb;
-        tb.build(logn);
         DevBuf<Fr> d;
         d.alloc(n);
         d.upload(data, n, 0);
         launch_fr_to_internal(d.p, n, 1, 0);          // x*2^256 -> x*2^261
+        if (ntt_pair_supported(logn) && !probe_env("ZKHIP_NTT_RADIX2")) {
+            // the proof path's own passes (nttpair.hip: register radix-8 butterflies, clean sub-transforms), the bit reversal
+            // folded into the middle pass's addressing: no permutation pass
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            std::lock_guard<std::mutex> lk(g_plain_mtx);
+            std::unique_ptr<NttPair> &tp = g_plain_tables[dev];
+            if (!tp || tp->L != logn) {
+                tp.reset(new NttPair());
+                tp->build(logn, logn, 0, 0, /*plain=*/true);
+            }
+            launch_ntt_plain(d.p, n, 1, *tp, inverse != 0, 0);
+            launch_fr_from_internal(d.p, n, 0);
+            HIP_TRY(hipMemcpy(data, d.p, n * 32, hipMemcpyDeviceToHost));
+            return;
+        }
+        // sizes the pipeline does not take (n < 8, n = 2^28): radix-2 passes + a permutation pass (ntt.hip)
+        Tables tb;
+        tb.build(logn);
         if (inverse) {
             launch_ntt_dif_inverse(d.p, n, 1, tb.t, 0);
             launch_bitrev_permute(d.p, logn, 0);

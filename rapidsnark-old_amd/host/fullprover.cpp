@@ -444,7 +444,8 @@ void FullProver::deviceLoop(size_t worker) {
             readyJobs.pop_front();
             jobs.push_back(job);
         }
-        const size_t depth = depthFor(circuits[job->circuit].header->domainSize);
+        size_t depth = depthFor(circuits[job->circuit].header->domainSize);
+        if (const uint32_t fits = circuits[job->circuit].replica[worker]->reservedInFlight()) depth = std::min(depth, (size_t)fits);
         {
             std::unique_lock<std::mutex> lk(wm);
             cv.wait(lk, [&] { return perCircuit[job->circuit] < depth; });

@@ -34,6 +34,7 @@ class Prover {
     zk_prover *h_ = nullptr;
     zk_multi_prover *m_ = nullptr;      // ZKHIP_DEVICES=0,1,...: one proof split over several GPUs
     uint32_t batch_ = 1;                // witnesses one submission may carry (zk_opts.batch)
+    uint32_t reserved_ = 0;             // proofs in flight whose workspace was allocated at creation (zk_prover_reserve); 0 = none asked for
 
 public:
     explicit Prover(zk_prover *h, uint32_t batch = 1) : h_(h), batch_(batch > 1 ? batch : 1) {}
@@ -68,6 +69,9 @@ public:
     // Small circuits: up to batch() witnesses of the circuit in ONE submission (zk_prove_batch_*): one set of kernel
     // launches for all of them.  r32 / s32 (optional) are used for every proof of the submission.
     uint32_t batch() const { return batch_; }
+    // makeProver(..., reserveInFlight): what could be reserved — the depth asked for, or 1 where that did not fit
+    uint32_t reservedInFlight() const { return reserved_; }
+    void setReserved(uint32_t n) { reserved_ = n; }
     void submitBatch(const std::vector<const void *> &wtns, const uint8_t *r32 = nullptr, const uint8_t *s32 = nullptr) {
         if (wtns.empty() || wtns.size() > batch_) throw std::invalid_argument("submitBatch: between 1 and batch() witnesses");
         if (m_) throw std::invalid_argument("submitBatch on a multi-GPU prover");
@@ -161,26 +165,37 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     // reserveInFlight (proverServer): the workspace of every proof slot and lane a pipeline of that depth walks is allocated
     // NOW (zk_prover_reserve) — slots and lanes otherwise appear when a depth is first reached, and a GPU whose tables
     // nearly fill its memory would create successfully and fail proofs later
-    auto create = [&] {
+    uint32_t reserved = 0;
+    auto create = [&](uint32_t reserve) {
         int rc = zk_prover_create(&h, &v, &o);
-        if (rc == 0 && reserveInFlight && (rc = zk_prover_reserve(h, reserveInFlight, 1)) != 0) {
+        if (rc == 0 && reserve && (rc = zk_prover_reserve(h, reserve, 1)) != 0) {
             zk_prover_destroy(h);
             h = nullptr;
         }
+        if (rc == 0) reserved = reserve;
         return rc;
     };
-    int rc = create();
+    auto oom = [] { return strstr(zk_last_error(), "out of memory") != nullptr; };
+    int rc = create(reserveInFlight);
     // window-precomputed tables are 13 x the table memory (2^26 constraints: > 288 GB): where they were only the DEFAULT
     // (proverServer) and they, or the proof workspace beside them, do not fit, the prover is created with the tables as they
     // are in the zkey instead of not at all
-    if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !pc && strstr(zk_last_error(), "out of memory")) {
+    if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !pc && oom()) {
         std::cerr << "window-precomputed tables do not fit the GPU's free memory: using the tables as in the zkey\n";
         o.flags &= ~(uint32_t)ZK_FLAG_PRECOMP;
         o.batch = 0;
-        rc = create();
+        rc = create(reserveInFlight);
+    }
+    // ... and where even then the workspace of a whole pipeline does not fit: one proof at a time (the caller reads the depth
+    // it may use from reservedInFlight())
+    if (rc != 0 && reserveInFlight > 1 && oom()) {
+        std::cerr << "the workspace of " << reserveInFlight << " proofs in flight does not fit the GPU's free memory: one proof at a time\n";
+        rc = create(1);
     }
     if (rc != 0) throw std::runtime_error(zk_last_error());
-    return std::unique_ptr<Prover>(new Prover(h, o.batch));
+    std::unique_ptr<Prover> pr(new Prover(h, o.batch));
+    pr->setReserved(reserved);
+    return pr;
 }
 
 }   // namespace Groth16

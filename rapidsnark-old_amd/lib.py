@@ -97,7 +97,8 @@ def load_library():
     lib.zk_prove_finish.argtypes = [C.c_void_p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_assemble.argtypes = [u8p, u8p, u8p, u8p, u8p, C.POINTER(zk_msm_sums), C.c_uint32, u8p, u8p, C.POINTER(zk_proof)]
     lib.zk_prover_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
-    lib.zk_prover_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    if hasattr(lib, "zk_prover_reserve"):      # (ZKHIP_LIB may name an older build of the library: same-box A/B runs)
+        lib.zk_prover_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.zk_multi_prover_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(zk_zkey_view), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(zk_opts)]
     lib.zk_multi_prover_destroy.argtypes = [C.c_void_p]
     lib.zk_multi_prover_destroy.restype = None

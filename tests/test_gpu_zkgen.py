@@ -75,6 +75,12 @@ def test_zkgen_tool_at_2p20_with_cli(zk, tmp_path):
     assert vk["protocol"] == "groth16" and vk["curve"] == "bn128" and len(vk["IC"]) == 3
     pub = json.load(open(tmp_path / "public.json"))
     assert len(pub) == 2
+    # the same files through the Groth16 VERIFICATION equation (oracle/pairing.py): needs neither the toxic waste nor any
+    # arithmetic of the product — once with the verification_key.json zkgen wrote, once with the .zkey's own sections 2 and 3
+    for vkfile in ("verification_key.json", "circuit.zkey"):
+        v = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refcheck", "verify.py"), str(tmp_path / "proof.json"), str(tmp_path / "public.json"),
+                            str(tmp_path / vkfile)], capture_output=True, text=True, timeout=300)
+        assert v.returncode == 0 and "OK: the proof verifies" in v.stdout, v.stdout + v.stderr
     r, s = 0x0123456789ABCDEF, (1 << 200) + 12345
     mp = zk.MultiProver(str(tmp_path / "circuit.zkey"), [0, 0, 0, 0], precomp=True)
     proof = mp.prove(str(tmp_path / "witness.wtns"), r, s)

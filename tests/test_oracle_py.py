@@ -1,11 +1,12 @@
 """CPU: the Python big-int oracle against its own committed golden vectors and the
 mathematical pins it stands on (SURVEY §A.2 constants, r*G = O, trapdoor check)."""
 import json
+import os
 import random
 
 import pytest
 
-from conftest import CIRCUITS, golden_bytes, golden_json
+from conftest import CIRCUITS, ROOT, golden_bytes, golden_json
 from oracle import bn254 as bn, groth16_ref as g
 from oracle.bn254 import G1, G2, R_MOD, Q_MOD
 
@@ -115,3 +116,42 @@ def test_eip196_public_vectors():
                       (8495653923123431417604973247489272438418190587263600148770280649306958101930,
                        4082367875863433681332203403145435568316851327593401208105741076214120093531))
     assert G2.is_on_curve(G2.gen) and G2.mul(G2.gen, R_MOD) is None
+
+
+# ---------------------------------------------------------------- pairing + Groth16 verification (oracle/pairing.py)
+def test_pairing_is_bilinear_nondegenerate_and_of_order_r():
+    from oracle import pairing as pr
+    e = pr.pairing(bn.G1_GEN, bn.G2_GEN)
+    assert e != pr.F12_ONE
+    assert pr.f12_pow(e, bn.R_MOD) == pr.F12_ONE
+    a, b = 0x1234567890abcdef1234, 0xfedcba98765432100123456789
+    P, Q = bn.G1.mul(bn.G1_GEN, a), bn.G2.mul(bn.G2_GEN, b)
+    assert pr.pairing(P, Q) == pr.f12_pow(e, a * b % bn.R_MOD)
+    assert pr.pairing(P, bn.G2_GEN) == pr.pairing(bn.G1_GEN, bn.G2.mul(bn.G2_GEN, a))
+    negP = (P[0], (-P[1]) % bn.Q_MOD)
+    assert pr.pairing_product_is_one([(P, Q), (negP, Q)])
+    assert not pr.pairing_product_is_one([(P, Q), (P, Q)])
+    assert pr.pairing(None, Q) == pr.F12_ONE
+
+
+def test_every_golden_proof_satisfies_the_groth16_verification_equation():
+    """Independent of the trapdoor and of every prover in this repository: e(A,B) = e(alpha,beta) e(vk_x,gamma) e(C,delta) with
+    the key's own section 2 / section 3 — and a proof with one coordinate changed, or another public input, does not."""
+    import importlib.util
+    import json as _json
+    spec = importlib.util.spec_from_file_location("refcheck_verify", os.path.join(ROOT, "tools", "refcheck", "verify.py"))
+    v = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(v)
+    from oracle import pairing as pr
+    for name in ("multiplier2", "r1cs_n8", "r1cs_nopub", "r1cs_n64", "r1cs_n256"):
+        d = os.path.join(ROOT, "tests", "golden", name)
+        assert v.verify_files(os.path.join(d, "proof.json"), os.path.join(d, "public.json"), os.path.join(d, "circuit.zkey")), name
+    d = os.path.join(ROOT, "tests", "golden", "multiplier2")
+    vk = v.load_vk(os.path.join(d, "circuit.zkey"))
+    pj = _json.load(open(os.path.join(d, "proof.json")))
+    pub = [int(x) for x in _json.load(open(os.path.join(d, "public.json")))]
+    A, B, C = v.g1(pj["pi_a"]), v.g2(pj["pi_b"]), v.g1(pj["pi_c"])
+    assert pr.groth16_verify(vk, pub, (A, B, C))
+    assert not pr.groth16_verify(vk, [pub[0] + 1] + pub[1:], (A, B, C))                   # another statement
+    assert not pr.groth16_verify(vk, pub, (bn.G1.dbl(A), B, C))                           # a valid point, the wrong one
+    assert not pr.groth16_verify(vk, pub, (A, B, (C[0], (C[1] + 1) % bn.Q_MOD)))          # not on the curve
