@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--witness", choices=["uniform", "realistic"], default="uniform",
                     help="uniform = BASELINE's random witness (worst case); realistic = 80%% {0,1}, 15%% < 2^32, 5%% full")
+    ap.add_argument("--shape", choices=["dense", "circuit"], default="dense",
+                    help="dense = BASELINE's family (nVars = domainSize, every table row a point); circuit = nVars = 3/4 of the domain + 5, "
+                         "3 public signals, ~30%% of the rows of A and of B1/B2 at infinity (rapidsnark_old_amd.synth)")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the also_realistic leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--precomp", type=int, default=1,
                     help="1 (default) = window-precomputed point tables resident in HBM (ZK_FLAG_PRECOMP: one-off work in create, like\n"
                          "the reference's makeProver it is outside the timed prove()); 0 = tables exactly as in the zkey")
@@ -90,7 +94,20 @@ def main():
     out = run(args)
     if out is None:                       # ranks > 0
         return
-    if args.gpus == 1 and args.log2n == 22 and not args.no_2p20 and not args.no_cpu and args.batch <= 1 and args.witness == "uniform":
+    default_run = args.gpus == 1 and args.log2n == 22 and not args.no_cpu and args.batch <= 1 and args.witness == "uniform" and args.shape == "dense"
+    if default_run and not args.no_realistic:
+        # what a REAL circom key and witness look like to the prover (BASELINE configs[4]'s fidelity; SURVEY section 8d's
+        # secondary line): the circuit-shaped member of the family with the 80/15/5 witness, timed the same way by the same code
+        import copy
+        a3 = copy.copy(args)
+        a3.witness, a3.shape, a3.no_cpu, a3.no_2p20, a3.no_realistic, a3.in_flight = "realistic", "circuit", True, True, True, 0
+        o3 = run(a3)
+        out["also_realistic"] = {kk: o3[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "resident_witness",
+                                                        "latency_ms_one_at_a_time", "stage_ms") if kk in o3}
+        out["also_realistic"]["note"] = ("same 2^22 domain; nVars = 3/4 n + 5, 3 public signals, ~30 % of the rows of A and of B1/B2 at infinity, witness 80 % in "
+                                         "{0,1} / 15 % < 2^32 / 5 % full-size: the MSM H and the six transforms cost what they cost in the headline, the four "
+                                         "witness MSMs shrink to their non-zero digits")
+    if default_run and not args.no_2p20:
         # BASELINE's metric is quoted "at 2^20 and 2^22": configs[1], timed the same way by the same code
         import copy
         a2 = copy.copy(args)
@@ -128,20 +145,18 @@ def run(args):
     dev = torch.device("cuda", local_rank)
     xdev = torch.device("cpu") if share else dev          # where the 384-byte records are exchanged
     dist = None
+    first_contact_info = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        first_contact_info = multi_gpu_first_contact(args, dist, torch, dev, xdev, rank, world, share)
 
     k = args.log2n
     n = 1 << k
     t0 = time.time()
     # --- synthetic zkey (tables generated by the product's GPU chain kernels)
-    wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes())
+    wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes(), shape=args.shape)
     t_gen = time.time() - t0
     t0 = time.time()
     partitioned = world in (2, 4, 8) and args.chain != "replicated" and k >= 6
@@ -182,7 +197,7 @@ def run(args):
     # the same for the resident-witness leg
     nw = args.steps + args.warmup
     n_wits = max(1, min(nw, (8 << 30) // (32 << k)))      # one per step while they fit 8 GiB of host memory (2^22: all 33), else cycled
-    wits_host = [synth.make_witness(k, seed=i, kind=args.witness) for i in range(n_wits)]
+    wits_host = [synth.make_witness(k, seed=i, kind=args.witness, n_vars=wl["nVars"]) for i in range(n_wits)]
     wits_dev = [torch.from_numpy(w).to(dev) for w in wits_host]
     torch.cuda.synchronize()
     pipelined = bool(args.pipeline)
@@ -388,7 +403,10 @@ def run(args):
     # streams' kernels share the chip meanwhile).  Algorithmic bytes: 96 per point (64 B affine point
     # + 32 B scalar, SURVEY §8d "one G1 MSM = 96*n").  `also`: the longest single launch, the G2
     # accumulation of MSM B2 (160 B per point).
-    config = {"workload": "synthetic BN254 zkey, 2^%d constraints (domainSize=nVars=2^%d, nPublic=1, nCoefs=%d), %s witness" % (k, k, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
+    shape_txt = ("domainSize=nVars=2^%d, nPublic=1" % k) if args.shape == "dense" else \
+        ("domainSize=2^%d, nVars=%d, nPublic=%d, ~30%% of the rows of A and of B1/B2 at infinity" % (k, wl["nVars"], wl["nPublic"]))
+    config = {"workload": "synthetic BN254 zkey, 2^%d constraints (%s, nCoefs=%d), %s witness" % (k, shape_txt, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
+              "shape": args.shape,
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
               "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
               "witnesses_per_submission": args.batch if (args.batch > 1 and world == 1 and not headline_hbm) else 1,
@@ -444,6 +462,7 @@ def run(args):
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, k, synth, prover, wits_host[0], wits_dev[0], args.cpu_budget_s)
     if world > 1:
+        out["first_contact"] = first_contact_info
         out["rccl_ranks"] = world
         out["exchange_backend"] = "gloo via the host (ZK_BENCH_SHARE_GPU test hook)" if share else "nccl (RCCL over xGMI)"
         if chain is not None:
@@ -515,7 +534,7 @@ def traffic_from_profiles(args, config, world, which):
         try:
             d = json.load(open(path))
             bc = d.get("bench", {}).get("config", {})
-            if all(bc.get(kk) == config.get(kk) for kk in keys) and d.get("bench", {}).get("n_gpus") == world:
+            if all(bc.get(kk) == config.get(kk) for kk in keys) and bc.get("shape", "dense") == config.get("shape") and d.get("bench", {}).get("n_gpus") == world:
                 for name, v in d["kernels"].items():
                     is_g2 = "k_msm_accum_l1_g2s" in name or ("k_msm_accum_l1" in name and "Fp2T" in name)
                     is_g1 = "k_msm_accum_l1" in name and not is_g2
@@ -524,6 +543,64 @@ def traffic_from_profiles(args, config, world, which):
         except (OSError, ValueError, KeyError):
             continue
     return None, "no counter pass committed for this configuration"
+
+
+def multi_gpu_first_contact(args, dist, torch, dev, xdev, rank, world, share):
+    """N > 1, BEFORE anything is built or timed: rendezvous with a deadline, then rapidsnark_old_amd.dist.first_contact — the
+    peer-access matrix, one all_to_all_single of the proof's real exchange size checked byte for byte against a host
+    reference, the 384-byte all_gather.  No multi-GPU path of this repository has run on more than one physical GPU
+    (DESIGN.md section 7): the first such run must say what it found instead of hanging or printing a wrong number.  Any
+    failure (a rank that never arrives, a collective that errors or delivers wrong bytes) ends EVERY rank with a non-zero
+    exit code; rank 0 prints the reason as its one JSON line."""
+    import datetime
+    import threading
+
+    def fail(reason, info=None):
+        if rank == 0:
+            print(json.dumps({"metric": "Groth16 proofs/sec", "value": None, "unit": "proofs/s", "n_gpus": world, "error": reason,
+                              "first_contact": info, "note": "multi-GPU first-contact check failed before the timed region (bench.py, multi_gpu_first_contact)"}), flush=True)
+        sys.stderr.write("[bench] rank %d: %s\n" % (rank, reason))
+        sys.stderr.flush()
+        os._exit(3)
+
+    deadline_s = float(os.environ.get("ZK_BENCH_RENDEZVOUS_S", "240"))
+    watchdog = threading.Timer(deadline_s + 60, lambda: fail("no progress for %.0f s in the rendezvous / first collectives (a rank missing or a hung collective)" % (deadline_s + 60)))
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        to = datetime.timedelta(seconds=deadline_s)
+        if share:
+            dist.init_process_group(backend="gloo", timeout=to)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=to)   # "nccl" is RCCL on ROCm
+    except Exception as exc:           # noqa: BLE001
+        fail("init_process_group failed: %s" % exc)
+    info = None
+    try:
+        from rapidsnark_old_amd.dist import first_contact
+        partitioned = world in (2, 4, 8) and args.chain != "replicated" and args.log2n >= 6
+        nloc = (1 << args.log2n) // world
+        xbytes = 3 * nloc * 32 if partitioned else 384 * world          # the chain's exchange buffer (a|b|c blocks), else just the records
+        xbytes = max(world, xbytes - xbytes % world)
+        exchange = None
+        if share:                        # single-GPU test hook: gloo on host tensors (all_gather, as the chain's own hook)
+            def exchange(dst, src):
+                allb = [torch.empty_like(src) for _ in range(world)]
+                dist.all_gather(allb, src)
+                part = src.numel() // world
+                dst.copy_(torch.cat([allb[sidx][rank * part:(rank + 1) * part] for sidx in range(world)]))
+        info = first_contact(dist, xdev, rank, world, xbytes, exchange=exchange)
+        info["chain_partitioned"] = bool(partitioned)
+        if not share:
+            nd = torch.cuda.device_count()
+            info["peer_access"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(nd)] for i in range(nd)]
+            info["visible_devices"] = nd
+    except Exception as exc:           # noqa: BLE001
+        fail("first contact failed: %s: %s" % (type(exc).__name__, exc), info)
+    watchdog.cancel()
+    if rank == 0:
+        sys.stderr.write("[bench] first contact: %s\n" % json.dumps(info))
+    return info
 
 
 def issue_bound_from_profiles(config, world, cus, clock, ms_per_step):
@@ -541,7 +618,7 @@ def issue_bound_from_profiles(config, world, cus, clock, ms_per_step):
         try:
             d = json.load(open(path))
             bc = d.get("bench_config", {})
-            if all(bc.get(kk) == config.get(kk) for kk in keys) and d.get("n_gpus") == world:
+            if all(bc.get(kk) == config.get(kk) for kk in keys) and bc.get("shape", "dense") == config.get("shape") and d.get("n_gpus") == world:
                 instr, per_kernel = d["valu_instructions_per_proof"], d.get("kernels")
                 src = "replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU pass of this command)" % os.path.relpath(path, ROOT)
                 break

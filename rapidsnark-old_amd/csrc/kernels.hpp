@@ -65,8 +65,10 @@ struct NttPair {
 bool ntt_pair_supported(uint32_t local_logn);
 // in place on `batch` vectors of 2^L elements, `stride_elems` apart: natural order in, natural order out
 void launch_ntt_coset_pair(Fr *data, uint64_t stride_elems, uint32_t batch, const NttPair &t, hipStream_t s);
-// one inverse (1/n included) or forward transform per vector on the same passes; `t` built with plain = true
-void launch_ntt_plain(Fr *data, uint64_t stride_elems, uint32_t batch, const NttPair &t, bool inverse, hipStream_t s);
+// one inverse (1/n included) or forward transform per vector on the same passes; `t` built with plain = true.  Input in
+// `data` (destroyed), result in `out` (another buffer of the same size: the bit reversal is folded into the middle pass's
+// addressing, which crosses workgroups).
+void launch_ntt_plain(Fr *out, Fr *data, uint64_t stride_elems, uint32_t batch, const NttPair &t, bool inverse, hipStream_t s);
 
 // fill the tables (device memory already allocated: n/2, n/2, n, 1 elements)
 void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, uint32_t logn, hipStream_t s);

@@ -612,7 +612,14 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
         bool started_before = offsets[b] < lo;
         typedef REGF FR;
         XYZZ<FR> acc = XYZZ<FR>::inf();
+#ifdef ZK_PROBE_LIMB_ROWS
+        // Measurement build (WRONG sums): what would tables resident in LIMB form buy?  Eighteen dwords are loaded per point (a
+        // 72-byte row, here read from the 64-byte-row table: the values are garbage, the loads and the instruction stream are
+        // those of a limb-form table) and used as the nine limbs of x and y as they are: no word -> limb unpacking.
+        struct { int32_t l[18]; } nextP;
+#else
         Affine<F> nextP;                 // raw words: the next point is in flight while this one is added
+#endif
         bool nextNeg = false, nextSkip = false;
         // two loads deep: the ENTRY of position e+2 is in flight while the POINT of e+1 is, so the address of a point
         // load never waits for its entry (a wave's three resident siblings run in phase with it — same work, same
@@ -628,19 +635,38 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
             nextSkip = idx < idx_min;
             bend2 = offsets[b + 2 < nbuckets_total ? b + 2 : nbuckets_total];
             const Affine<F> *src = points + (nextSkip ? 0 : ZK_GATHER_ROW(idx - idx_sub));
+#ifdef ZK_PROBE_LIMB_ROWS
+            {
+                const uint4 *q4 = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint4 t4 = q4[i];
+                    nextP.l[4 * i] = (int32_t)t4.x; nextP.l[4 * i + 1] = (int32_t)t4.y; nextP.l[4 * i + 2] = (int32_t)t4.z; nextP.l[4 * i + 3] = (int32_t)t4.w;
+                }
+                const uint2 t2 = *reinterpret_cast<const uint2 *>(q4 + 4);
+                nextP.l[16] = (int32_t)t2.x; nextP.l[17] = (int32_t)t2.y;
+            }
+#else
             nextP.x = load_el(&src->x);
             nextP.y = load_el(&src->y);
+#endif
             entNext = entries[pos + 1 < hi ? pos + 1 : hi - 1];
         };
         uint32_t e = lo;
         fetch(e);
         while (e < hi) {
-            Affine<F> Pw = nextP;
+            auto Pw = nextP;
             bool ng = nextNeg, skip = nextSkip;
             e++;
             fetch(e < hi ? e : hi - 1);
             if (!skip) {
+#ifdef ZK_PROBE_LIMB_ROWS
+                Affine<FR> P;
+#pragma unroll
+                for (int i = 0; i < 9; i++) { P.x.l[i] = Pw.l[i]; P.y.l[i] = Pw.l[9 + i]; }
+#else
                 Affine<FR> P = to_reg_affine<F>(Pw);
+#endif
                 if (ng) negate_y(P);
                 madd(acc, P);          // curve29.hpp: bound-tracked specialisation
             }

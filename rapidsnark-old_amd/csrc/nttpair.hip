@@ -277,8 +277,9 @@ struct PairDev {
 // from their natural positions, DIT, * T.  Position p = tile << m | p0 of the bit-reversed order holds index
 // brev_m(p0) << t | brev_t(tile): the permutation costs no pass, only the coalescing of one side of this kernel (32-byte
 // accesses 2^t elements apart).
+// MODE 1 / 2 permute across workgroups: they read `src` and write `data`, two DIFFERENT buffers (MODE 0: the same, in place).
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_elems, PairDev t) {
+__global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, const Fr *src, uint64_t stride_elems, PairDev t) {
     extern __shared__ int32_t lds[];
     typedef Fr29 F;
     // The vectors (a, b, c) of a tile run next to each other ON THE SAME XCD (workgroup i goes to XCD i mod 8, each XCD has
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_el
         tile = blockIdx.x / t.batch;
     }
     Fr *xg = data + (uint64_t)vec * stride_elems;
+    const Fr *xs = MODE == 0 ? xg : src + (uint64_t)vec * stride_elems;
     const uint32_t T = threadIdx.x;
     const uint64_t wg_base = (uint64_t)tile << 11;
     const uint32_t wtop = t.plan.wlo[t.plan.nph - 1];            // DIF starts (and DIT ends) in the top window: coalesced
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, uint64_t stride_el
     for (int k = 0; k < 8; k++) {
         const uint32_t v = v_of(T, k, wfirst);
         const uint64_t pos = MODE == 2 ? natural(v) : wg_base + v;
-        x[k] = active ? F::load(pload_el(xg + pos)) : F::zero();
+        x[k] = active ? F::load(pload_el(xs + pos)) : F::zero();
     }
     if (MODE != 2 && t.tinv) {
 #pragma unroll
@@ -557,7 +559,7 @@ static void run_outer(Fr *data, uint64_t stride, uint32_t batch, const NttPair &
 }
 
 template <int MODE>
-static void run_mid(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, hipStream_t s) {
+static void run_mid(Fr *data, const Fr *src, uint64_t stride, uint32_t batch, const NttPair &tb, hipStream_t s) {
     const uint32_t t = tb.L - tb.m;
     lds_opt_in();
     PairDev d;
@@ -575,7 +577,7 @@ static void run_mid(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb
     const uint32_t wgs = (uint32_t)(((1ull << tb.L) + 2047) >> 11);
     d.tiles = wgs;
     const size_t shmem = (size_t)9 * 2048 * 4;
-    hipLaunchKernelGGL(k_ntt_mid<MODE>, dim3(wgs * batch), dim3(256), shmem, s, data, stride, d);
+    hipLaunchKernelGGL(k_ntt_mid<MODE>, dim3(wgs * batch), dim3(256), shmem, s, data, src, stride, d);
     ZK_LAUNCH_OK("ntt middle pass");
 }
 template <bool DIF>
@@ -601,20 +603,22 @@ static void run_outer_passes(Fr *data, uint64_t stride, uint32_t batch, const Nt
 // a | b | c (batch vectors `stride` elements apart, nloc = 2^L elements each): in place, natural order in and out
 void launch_ntt_coset_pair(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, hipStream_t s) {
     run_outer_passes<true>(data, stride, batch, tb, s);
-    run_mid<0>(data, stride, batch, tb, s);
+    run_mid<0>(data, data, stride, batch, tb, s);
     run_outer_passes<false>(data, stride, batch, tb, s);
 }
 
 // ONE transform per vector, natural order in and out, on the same passes (tables built with plain = true): the inverse
 // (1/n included) is the outer DIF passes + the middle pass storing at natural positions, the forward the middle pass
 // gathering from natural positions + the outer DIT passes.  No permutation pass, no per-call table build.
-void launch_ntt_plain(Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, bool inverse, hipStream_t s) {
+// The permutation crosses workgroups, so the middle pass works out of place: the result is left in `out` (as large as `data`,
+// which is used as scratch).
+void launch_ntt_plain(Fr *out, Fr *data, uint64_t stride, uint32_t batch, const NttPair &tb, bool inverse, hipStream_t s) {
     if (inverse) {
         run_outer_passes<true>(data, stride, batch, tb, s);
-        run_mid<1>(data, stride, batch, tb, s);
+        run_mid<1>(out, data, stride, batch, tb, s);
     } else {
-        run_mid<2>(data, stride, batch, tb, s);
-        run_outer_passes<false>(data, stride, batch, tb, s);
+        run_mid<2>(out, data, stride, batch, tb, s);
+        run_outer_passes<false>(out, stride, batch, tb, s);
     }
 }
 

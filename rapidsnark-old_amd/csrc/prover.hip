@@ -886,11 +886,12 @@ struct BatchIn {
     const uint8_t *r32s, *s32s;
 };
 
-// ZKHIP_LONE_ORDER=0/1 (-DZK_PROBES builds): same-box A/B of the lone-proof launch order
+// ZKHIP_LONE_ORDER=1 (-DZK_PROBES builds only): the witness MSMs of a lone proof enqueued BEHIND the transform chain.
+// Measured and left off (profiles/r04c_ab_lone_order.txt, same box, three alternations of six synchronous proofs):
+// 2^22 40.4 / 40.0 / 39.7 ms with, 39.4 / 39.9 / 39.4 without; 2^20 13.4 / 13.3 / 13.8 vs 13.1 / 14.6 / 13.6.
 static bool lone_order(const zk_prover *p) {
     static const int forced = [] { const char *e = probe_env("ZKHIP_LONE_ORDER"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced != 0;
-    return p->shard_count == 1 && !p->part && p->logn >= 18;
+    return forced > 0 && p->shard_count == 1 && !p->part;
 }
 
 // MSM B2, A, B1 over the shared bucket order of sort(w), on stream 2 (src/groth16.cpp:180-197)
@@ -1009,13 +1010,12 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     }
     q.sort_w.run(d_wtns + p->sv.lo, s2);
     HIP_TRY(hipEventRecord(q.ev_sortw, s2));
-    // A LONE proof (nothing else in flight, unsharded, large): the witness MSMs wait for the end of the transform chain.
-    // Their first launch, the G2 accumulation, is ONE round of workgroups that hold every register of the chip for its whole
-    // 11 ms: started beside the chain it starves the chain's last pass (0.9 ms of work took 16.6 ms,
-    // profiles/r04a_lone_proof_timeline_2p22.txt), so h, sort(h) and MSM H only began when MSM A was already done, and
-    // 3 ms of merges, reductions and sort(h) ended up exposed between the level-1 launches instead of beside them.
-    // Behind the chain (3.9 ms beside sort(w), which it hides) both streams have level-1 launches to alternate from
-    // then on.  With other proofs in flight their kernels fill these gaps and the order does not matter.
+    // Experiment (off: lone_order): the witness MSMs of a LONE proof enqueued behind the transform chain.  The idea: the G2
+    // accumulation is ONE round of workgroups that hold every register of the chip for its whole 11 ms — started beside the
+    // chain it starves the chain's last pass (0.9 ms of work took 16.6 ms, profiles/r04a_lone_proof_timeline_2p22.txt), so h,
+    // sort(h) and MSM H only begin when MSM A is done.  Behind the chain the starved kernel is sort(h)'s partition pass instead
+    // (9.4 ms beside the G2 launch, profiles/r04b_lone_proof_timeline_2p22.txt) and the proof is no shorter: a lone proof is
+    // bound by the SUM of its chip-filling kernels, not by their order.
     q.defer_w = lone_order(p) && !p->capturing && !p->use_graph && p->in_flight == 0 && s2 != s && !p->batch_abc;
     if (!q.defer_w) enqueue_witness_msms(p, c);
 
@@ -1924,9 +1924,11 @@ int zk_fr_ntt(uint8_t *data, uint64_t n, int inverse) {
                 tp.reset(new NttPair());
                 tp->build(logn, logn, 0, 0, /*plain=*/true);
             }
-            launch_ntt_plain(d.p, n, 1, *tp, inverse != 0, 0);
-            launch_fr_from_internal(d.p, n, 0);
-            HIP_TRY(hipMemcpy(data, d.p, n * 32, hipMemcpyDeviceToHost));
+            DevBuf<Fr> d2;
+            d2.alloc(n);
+            launch_ntt_plain(d2.p, d.p, n, 1, *tp, inverse != 0, 0);
+            launch_fr_from_internal(d2.p, n, 0);
+            HIP_TRY(hipMemcpy(data, d2.p, n * 32, hipMemcpyDeviceToHost));
             return;
         }
         // sizes the pipeline does not take (n < 8, n = 2^28): radix-2 passes + a permutation pass (ntt.hip)

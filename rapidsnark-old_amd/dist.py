@@ -127,3 +127,69 @@ class ShardedChain:
             self._phase_events.append(self._cur)
             if len(self._phase_events) > 256:
                 self._phase_events.pop(0)
+
+
+def first_contact(dist, device, rank, world, exchange_bytes, exchange=None, gather=None):
+    """What the FIRST run on a real multi-GPU node should say about itself before anything is timed (nothing in this
+    repository has ever met a second GPU: DESIGN.md section 7).  On every rank; -> dict (the same on every rank):
+      peer_access           matrix [i][j] = torch.cuda.can_device_access_peer(i, j) over the devices this process sees
+                            (what zk_multi_prover's peer writes need; the one-process-per-GPU path needs only RCCL)
+      all_to_all_bytes_ok   ONE all_to_all_single on a buffer of the proof's real exchange size (exchange_bytes per rank, uint8
+                            views as ShardedChain uses them), every byte a function of (source rank, destination rank, offset),
+                            checked on the receiver against a HOST-computed reference, byte for byte
+      all_gather_ok         the 384-byte partial-sum record path (gather_partials) with a rank-stamped payload
+      all_to_all_ms / all_to_all_GBps_per_rank   second, timed run of the same exchange
+    A collective that fails or a mismatch raises: the caller turns it into a non-zero exit with the reason in its JSON line."""
+    import time
+    out = {"world": world, "backend": dist.get_backend(), "exchange_bytes_per_rank": int(exchange_bytes)}
+    if device.type == "cuda":
+        nd = torch.cuda.device_count()
+        out["visible_devices"] = nd
+        out["peer_access"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(nd)] for i in range(nd)]
+        out["device_name"] = torch.cuda.get_device_name(device)
+    part = exchange_bytes // world
+    if part == 0 or exchange_bytes % world:
+        raise ValueError("exchange buffer of %d bytes does not split into %d parts" % (exchange_bytes, world))
+    idx = np.arange(part, dtype=np.uint64)
+
+    def pattern(src, dst):              # byte k of the chunk rank `src` sends to rank `dst` (host reference)
+        return ((idx * 2654435761 + src * 131 + dst * 17 + (idx >> 11)) % 251).astype(np.uint8)
+
+    send_host = np.concatenate([pattern(rank, d) for d in range(world)])
+    want_host = np.concatenate([pattern(s_, rank) for s_ in range(world)])
+    send = torch.from_numpy(send_host).to(device)
+    recv = torch.zeros(exchange_bytes, dtype=torch.uint8, device=device)
+    xch = exchange or (lambda dst, src: dist.all_to_all_single(dst, src))
+    xch(recv, send)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    got = recv.cpu().numpy()
+    bad = int((got != want_host).sum())
+    # every rank learns whether ANY rank saw wrong bytes (so that all of them stop together instead of one leaving the
+    # others inside the next collective)
+    flag = torch.tensor([0 if bad else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    out["all_to_all_bytes_ok"] = int(flag.item()) == 1
+    if bad:
+        first = int(np.nonzero(got != want_host)[0][0])
+        raise RuntimeError("all_to_all_single delivered %d wrong bytes on rank %d (first at offset %d: chunk of source rank %d)" % (bad, rank, first, first // part))
+    if not out["all_to_all_bytes_ok"]:
+        raise RuntimeError("all_to_all_single delivered wrong bytes on another rank (this rank's %d bytes are right)" % exchange_bytes)
+    t0 = time.perf_counter()
+    xch(recv, send)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["all_to_all_ms"] = round(dt * 1e3, 3)
+    out["all_to_all_GBps_per_rank"] = round(exchange_bytes * (world - 1) / world / dt / 1e9, 2)
+    # the 384-byte record path
+    rec = bytes([(rank * 37 + i) % 256 for i in range(PARTIAL_BYTES)])
+    if gather is not None:
+        parts = gather(rec)
+    else:
+        parts = gather_partials(rec, dist, device)
+    ok = all(parts[r_] == bytes([(r_ * 37 + i) % 256 for i in range(PARTIAL_BYTES)]) for r_ in range(world))
+    out["all_gather_ok"] = ok
+    if not ok:
+        raise RuntimeError("all_gather of the partial-sum records returned wrong bytes on rank %d" % rank)
+    return out

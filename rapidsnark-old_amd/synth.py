@@ -59,15 +59,15 @@ def random_fr_bytes(rng: np.random.Generator, n: int) -> np.ndarray:
     return out.view(np.uint8).reshape(n, 32)
 
 
-def make_coefs(k: int, n_public: int, seed: int) -> np.ndarray:
-    """Section-4 image (u32 count + packed records) as a flat uint8 array."""
+def make_coefs(k: int, n_public: int, seed: int, n_vars: int = 0) -> np.ndarray:
+    """Section-4 image (u32 count + packed records) as a flat uint8 array (signals drawn below n_vars, default the domain size)."""
     n = 1 << k
     m = n - n_public - 1
     rng = np.random.default_rng(0xC0EF0000 + k + seed)
     ncoefs = 4 * m + n_public + 1
     rec = np.zeros(ncoefs, dtype=COEF_DTYPE)
     rows = np.arange(m, dtype=np.uint32)
-    cols = rng.integers(0, n, size=(m, 4), dtype=np.uint32)
+    cols = rng.integers(0, n_vars or n, size=(m, 4), dtype=np.uint32)
     vals = random_fr_bytes(rng, 4 * m).reshape(m, 4, 32)
     for j in range(4):                       # j = 0,1 -> matrix A ; 2,3 -> matrix B
         sl = rec[j * m:(j + 1) * m]
@@ -89,12 +89,18 @@ def make_coefs(k: int, n_public: int, seed: int) -> np.ndarray:
     return img
 
 
-def make_witness(k: int, seed: int = 0, kind: str = "uniform") -> np.ndarray:
-    """nVars x 32 B standard form, w[0] = 1.
+def circuit_n_vars(k: int) -> int:
+    """nVars of the circuit-shaped member of the family: three quarters of the domain and not a power of two
+    (real circom keys never have nVars = domainSize: the domain is the next power of two above the constraint count)."""
+    return 3 * (1 << k) // 4 + 5
+
+
+def make_witness(k: int, seed: int = 0, kind: str = "uniform", n_vars: int = 0) -> np.ndarray:
+    """nVars x 32 B standard form, w[0] = 1 (n_vars = 0: the domain size 2^k).
     kind = "uniform"   : every other entry uniform in [0, r)  — the worst case for the MSMs
     kind = "realistic" : SURVEY §8d secondary line: 80 % of entries in {0, 1}, 15 % < 2^32, 5 % full-size
                          (circom witnesses are dominated by booleans and small values)."""
-    n = 1 << k
+    n = n_vars or (1 << k)
     rng = np.random.default_rng(0x5EED0000 + k + 1000003 * seed)
     w = random_fr_bytes(rng, n)
     if kind == "realistic":
@@ -111,11 +117,21 @@ def make_witness(k: int, seed: int = 0, kind: str = "uniform") -> np.ndarray:
     return w.reshape(-1)
 
 
-def workload(k, chain_g1, chain_g2, g1_mul, g2_mul, g1_gen, g2_gen, n_public=1, seed=0):
+def workload(k, chain_g1, chain_g2, g1_mul, g2_mul, g1_gen, g2_gen, n_public=1, seed=0, shape="dense"):
     """-> dict usable as a zkey view: numpy uint8 arrays for every section + the dlog table.
 
     chain_gX(n, P0_bytes, Q_bytes) -> uint8 array; gX_mul(P_bytes, k_int) -> bytes.
+    shape = "dense"   : BASELINE's worst case — nVars = domainSize, every table row a distinct point
+    shape = "circuit" : what a real circom key looks like to the prover — nVars = 3/4 of the domain + 5 (not a power of
+                        two), 3 public signals, and ~30 % of the rows of A and of B1 / B2 (the SAME rows in both: B1_i and B2_i
+                        are b_i(tau) in the two groups) all-zero = the point at infinity: wires that never occur in that
+                        matrix.  `zero_rows` holds the masks; the discrete logs of the other rows are unchanged, so every
+                        MSM result stays checkable in Fr (expected_msm_dlogs).
     """
+    if shape == "circuit":
+        return _circuit_workload(k, chain_g1, chain_g2, g1_mul, g2_mul, g1_gen, g2_gen, seed)
+    if shape != "dense":
+        raise ValueError("unknown workload shape %r" % shape)
     n = 1 << k
     prng = random.Random(0xD106 + 31 * k + seed)
     dl = {name: (prng.randrange(1, R_MOD), prng.randrange(1, R_MOD)) for name in ("A", "B", "C", "H")}
@@ -142,6 +158,25 @@ def workload(k, chain_g1, chain_g2, g1_mul, g2_mul, g1_gen, g2_gen, n_public=1, 
     return wl
 
 
+def _circuit_workload(k, chain_g1, chain_g2, g1_mul, g2_mul, g1_gen, g2_gen, seed):
+    n_public = 3
+    nv = circuit_n_vars(k)
+    wl = workload(k, chain_g1, chain_g2, g1_mul, g2_mul, g1_gen, g2_gen, n_public=n_public, seed=seed)     # dense tables of 2^k rows to cut from
+    rng = np.random.default_rng(0xC1AC0000 + 7 * k + seed)
+    za, zb = rng.random(nv) < 0.30, rng.random(nv) < 0.30
+    za[0] = zb[0] = False
+    for name, rows, mask in (("pointsA", 64, za), ("pointsB1", 64, zb), ("pointsB2", 128, zb)):
+        t = np.array(wl[name][:nv * rows]).reshape(nv, rows)
+        t[mask] = 0                                   # all-zero = infinity
+        wl[name] = t.reshape(-1)
+    wl["pointsC"] = np.ascontiguousarray(wl["pointsC"][:(nv - n_public - 1) * 64])
+    wl["nVars"] = nv
+    wl["coefs"] = make_coefs(k, n_public, seed, n_vars=nv)
+    wl["zero_rows"] = {"A": za, "B": zb}
+    wl["shape"] = "circuit"
+    return wl
+
+
 def weighted_sums(vals: np.ndarray):
     """(sum v_i, sum i*v_i) over 32-byte LE integers, exact (16-bit limbs, chunked uint64 dots)."""
     v = np.ascontiguousarray(vals).view(np.uint8).reshape(-1, 32).view("<u2").astype(np.uint64)    # [n,16]
@@ -163,9 +198,13 @@ def weighted_sums(vals: np.ndarray):
 def expected_msm_dlogs(wl, witness: np.ndarray, h: np.ndarray):
     """Discrete logs (mod r) of the five MSM results for a workload() data set."""
     npub = wl["nPublic"]
-    sw, swi = weighted_sums(witness)
     out = {}
     for name, key in (("pi_a", "A"), ("pib1", "B")):
+        wm = np.ascontiguousarray(witness).reshape(-1, 32)
+        if "zero_rows" in wl:                         # rows at infinity contribute nothing
+            wm = wm.copy()
+            wm[wl["zero_rows"][key]] = 0
+        sw, swi = weighted_sums(wm)
         k0, kq = wl["dlogs"][key]
         out[name] = (k0 * sw + kq * swi) % R_MOD
     out["pi_b"] = out["pib1"]

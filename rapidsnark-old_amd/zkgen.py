@@ -80,15 +80,27 @@ def _sum_mod(vals):
     return synth.weighted_sums(vals)[0] % R_MOD
 
 
-def generate(k, n_public=2, seed=0):
+def _small_fr(rng, count, bits):
+    """count values below 2^bits (bits <= 32) as standard-form 32-byte rows"""
+    out = np.zeros((count, 32), dtype=np.uint8)
+    out[:, :4] = rng.integers(0, 1 << bits, size=count, dtype=np.uint64).astype("<u4").view(np.uint8).reshape(count, 4)
+    return out
+
+
+def generate(k, n_public=2, seed=0, circuit_like=False):
     """-> dict with the zkey sections (numpy uint8), the witness, the trapdoor and the vectors the
-    trapdoor check needs.  Needs a GPU."""
+    trapdoor check needs.  Needs a GPU.
+
+    circuit_like: what circom circuits look like instead of uniformly random everything — nVars = 3/4 of the domain + 5
+    (never the domain size); 80 % of the signals boolean (inputs drawn from {0,1}, internal signals the AND of two boolean
+    inputs), 15 % small (16-bit coefficients on small inputs), 5 % full-size; a second layer of constraints reads the first
+    layer's outputs; wires that never occur in A (or in B) leave all-zero rows = points at infinity in those tables."""
     n = 1 << k
     n_in = max(n_public + 1, n // 8)                 # input signals (incl. the public ones)
-    m = n - 1 - n_in                                 # constraints = internal signals
+    m = (3 * n // 4 + 5 if circuit_like else n) - 1 - n_in      # constraints = internal signals
     if m < 1 or m + n_public + 1 > n:
         raise ValueError("domain too small")
-    n_vars = 1 + n_in + m                            # = n
+    n_vars = 1 + n_in + m                            # = n (circuit_like: 3n/4 + 5)
     rng = np.random.default_rng(0x2C6E0000 + 131 * k + seed)
     import random
     prng = random.Random(0x70C51C + 977 * k + seed)
@@ -97,6 +109,33 @@ def generate(k, n_public=2, seed=0):
     # ---- circuit
     p, q, u = (rng.integers(0, 1 + n_in, size=m, dtype=np.uint32) for _ in range(3))
     a1, a2, b1, b2 = (synth.random_fr_bytes(rng, m).reshape(-1) for _ in range(4))          # standard values
+    w_in = synth.random_fr_bytes(rng, n_in)
+    layer2 = np.zeros(m, dtype=bool)
+    if circuit_like:
+        cls_in = rng.random(n_in)
+        w_in[cls_in < 0.80] = _small_fr(rng, int((cls_in < 0.80).sum()), 1)
+        mid_in = (cls_in >= 0.80) & (cls_in < 0.95)
+        w_in[mid_in] = _small_fr(rng, int(mid_in.sum()), 32)
+        bool_in = (1 + np.nonzero(cls_in < 0.80)[0]).astype(np.uint32)                      # signal numbers of the boolean inputs
+        small_in = (1 + np.nonzero(cls_in < 0.95)[0]).astype(np.uint32)
+        cls = rng.random(m)
+        is_and, is_small = cls < 0.80, (cls >= 0.80) & (cls < 0.95)
+        one, zero = np.zeros((1, 32), np.uint8), np.zeros((1, 32), np.uint8)
+        one[0, 0] = 1
+        A1, A2, B1c, B2c = (x.reshape(m, 32) for x in (a1, a2, b1, b2))
+        # AND of two boolean inputs: (1 w_p + 0) * (1 w_u + 0) = w_out
+        p[is_and] = rng.choice(bool_in, size=int(is_and.sum()))
+        u[is_and] = rng.choice(bool_in, size=int(is_and.sum()))
+        A1[is_and], A2[is_and], B1c[is_and], B2c[is_and] = one, zero, one, zero
+        # small arithmetic: 16-bit coefficients on small inputs (products stay far below 2^128)
+        ns = int(is_small.sum())
+        p[is_small], q[is_small], u[is_small] = (rng.choice(small_in, size=ns) for _ in range(3))
+        A1[is_small], A2[is_small], B1c[is_small], B2c[is_small] = (_small_fr(rng, ns, 16) for _ in range(4))
+        # the rest: full-size coefficients; in the second half of the constraints they read the FIRST half's outputs
+        layer2 = (~is_and) & (~is_small) & (np.arange(m) >= m // 2)
+        nl2 = int(layer2.sum())
+        p[layer2], q[layer2], u[layer2] = (rng.integers(1 + n_in, 1 + n_in + m // 2, size=nl2, dtype=np.uint32) for _ in range(3))
+        a1, a2, b1, b2 = (x.reshape(-1) for x in (A1, A2, B1c, B2c))
     r3 = _const(MONT ** 3, m)
     a1m, a2m, b1m, b2m = (_mul(x, r3) for x in (a1, a2, b1, b2))                             # value * R^2: the zkey's coefficient form
     rows = np.arange(m, dtype=np.uint32)
@@ -106,17 +145,21 @@ def generate(k, n_public=2, seed=0):
     recA = np.concatenate([_records(0, rows, p, a1m), _records(0, rows, q, a2m),
                            _records(0, extra_rows, np.arange(n_public + 1, dtype=np.uint32), np.tile(one_r2, n_public + 1))])
     recB = np.concatenate([_records(1, rows, u, b1m), _records(1, rows, np.zeros(m, np.uint32), b2m)])
+    if circuit_like:                                # a real zkey holds no zero coefficients
+        recA = recA[recA["v"].max(axis=1) > 0]
+        recB = recB[recB["v"].max(axis=1) > 0]
     rec = np.concatenate([recA, recB])
     rec = rec[rng.permutation(rec.size)]            # the loader must not rely on any order
     coefs = _image(rec)
 
-    # ---- witness: inputs random, internal signals = (A.w) o (B.w)
+    # ---- witness: inputs random, internal signals = (A.w) o (B.w) (a second pass once the first layer's outputs exist)
     w = np.zeros((n_vars, 32), dtype=np.uint8)
     w[0, 0] = 1
-    w[1:1 + n_in] = synth.random_fr_bytes(rng, n_in)
-    am, bm = L.fr_coef_accumulate(coefs, rec.size, n, w.reshape(-1))
-    prod = _mul(_mul(am[:m * 32], bm[:m * 32]), _const(1, m))                                # (aR)(bR)/R /R = ab
-    w[1 + n_in:] = prod.reshape(-1, 32)
+    w[1:1 + n_in] = w_in
+    for _pass in range(2 if layer2.any() else 1):
+        am, bm = L.fr_coef_accumulate(coefs, rec.size, n, w.reshape(-1))
+        prod = _mul(_mul(am[:m * 32], bm[:m * 32]), _const(1, m))                            # (aR)(bR)/R /R = ab
+        w[1 + n_in:] = prod.reshape(-1, 32)
     w = w.reshape(-1)
 
     # ---- Fr half of the setup

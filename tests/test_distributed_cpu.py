@@ -92,3 +92,55 @@ def test_two_rank_sharded_proof_over_gloo(name):
         assert p.exitcode == 0
     ok, nparts = q.get(timeout=5)
     assert ok and nparts == 2
+
+
+def _fc_worker(rank, world, port, corrupt, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rapidsnark_old_amd  # noqa: F401
+        from rapidsnark_old_amd.dist import first_contact
+        exchange = None
+        if corrupt:
+            def exchange(dst, src):
+                dist.all_to_all_single(dst, src)
+                if rank == 1:
+                    dst[dst.numel() // 2 + 5] ^= 0x40          # one flipped bit in the chunk that came from rank 1
+        try:
+            info = first_contact(dist, torch.device("cpu"), rank, world, 3 * 1024 * 32, exchange=exchange)
+            q.put((rank, "ok", info))
+        except RuntimeError as exc:
+            q.put((rank, "error", str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_first_contact_kit_checks_the_exchange_byte_for_byte(corrupt):
+    """rapidsnark_old_amd.dist.first_contact (what bench.py --gpus N runs before it times anything): world_size 2 over gloo —
+    the all_to_all of the chain's exchange buffer against the host-computed pattern, the 384-byte all_gather; a single
+    flipped bit on one rank is reported by that rank with the offset and the source rank."""
+    world = 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fc_worker, args=(r, world, port, corrupt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (st, info)) for r, st, info in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(60)
+    if not corrupt:
+        for r in range(world):
+            st, info = res[r]
+            assert st == "ok" and info["all_to_all_bytes_ok"] and info["all_gather_ok"] and info["world"] == 2 and info["backend"] == "gloo"
+            assert info["exchange_bytes_per_rank"] == 3 * 1024 * 32 and info["all_to_all_ms"] > 0
+    else:
+        assert res[0][0] == "error" and "another rank" in res[0][1]          # every rank stops, the faulty one says where
+        st, msg = res[1]
+        assert st == "error" and "1 wrong bytes on rank 1" in msg and "source rank 1" in msg

@@ -174,6 +174,11 @@ def test_bench_multi_rank_path_on_one_gpu(ranks, k):
     assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["rccl_ranks"] == ranks and d["steps"] == 4
+    # the first-contact kit ran before anything was timed: rendezvous, one all_to_all of the proof's exchange size checked
+    # byte for byte against a host reference, the 384-byte all_gather
+    fc = d["first_contact"]
+    assert fc["world"] == ranks and fc["all_to_all_bytes_ok"] is True and fc["all_gather_ok"] is True and fc["chain_partitioned"] is True
+    assert fc["exchange_bytes_per_rank"] == 3 * ((1 << k) // ranks) * 32 and fc["all_to_all_ms"] > 0 and fc["backend"] == "gloo"
     assert d["multi_gpu_proof_equals_single_gpu_proof"] is True
     assert "chain partitioned" in d["config"]["parallelism"] and d["config"]["witness_upload"].startswith("each rank uploads 1/N")
     assert set(d["exchange_ms"]) == {"witness_all_gather", "all_to_all_1_to_cross_inverse", "all_to_all_2_to_local",

@@ -239,3 +239,28 @@ def test_irregular_shapes_bit_exact_vs_c_oracle(zk, k, n_vars, n_public, precomp
     assert p.prove_msm_dev(wd.data_ptr()) == co.prove_msm(view, w)
     assert p.prove_dev(wd.data_ptr(), r, s) == co.prove(view, w, r, s)
     p.lib.zk_prover_destroy(p.h)
+
+
+@pytest.mark.parametrize("precomp", [False, True])
+def test_circuit_shaped_key_bit_exact_vs_c_oracle(zk, precomp):
+    """The circuit-shaped member of the family (synth.workload(shape="circuit"): nVars = 3/4 of the domain + 5, three public
+    signals, ~30 % of the rows of A and of B1 / B2 at infinity) with the 80/15/5 witness — what bench.py's `also_realistic`
+    leg times at 2^22 — at 2^14 against the C restatement: the five MSM sums, the assembled proof (host-witness entry point,
+    as the reference's prove(wtns)), and the known-discrete-log prediction of the MSM sums."""
+    import torch
+    from rapidsnark_old_amd import synth
+    k = 14
+    wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes(), shape="circuit")
+    w = synth.make_witness(k, seed=11, kind="realistic", n_vars=wl["nVars"])
+    view = co.ZkeyView(wl)
+    p = _prover(zk, wl, precomp=precomp)
+    wd = torch.from_numpy(w).to("cuda:0")
+    r, s = 0xC1AC017, (1 << 190) + 7
+    sums = p.prove_msm_dev(wd.data_ptr())
+    assert sums == co.prove_msm(view, w)
+    want = synth.expected_msm_dlogs(wl, w, np.zeros(32, dtype=np.uint8))
+    assert sums[64:128] == zk.g1_mul(G1B, want["pi_a"]) and sums[192:320] == zk.g2_mul(G2B, want["pi_b"]) and sums[320:384] == zk.g1_mul(G1B, want["pi_c"])
+    ref = co.prove(view, w, r, s)
+    assert p.prove_dev(wd.data_ptr(), r, s) == ref
+    assert p.prove_host(w, r, s) == ref
+    p.lib.zk_prover_destroy(p.h)

@@ -66,6 +66,50 @@ def test_generated_key_is_valid(zk, k, npub):
     assert [[int(x) for x in pair] for pair in vk["vk_gamma_2"][:2]] == [list(g2[0]), list(g2[1])]
 
 
+def test_circuit_like_key_is_valid_sparse_and_verifies(zk):
+    """zkgen.generate(circuit_like=True): nVars = 3/4 of the domain + 5, a witness dominated by booleans, all-zero rows in
+    A / B1 / B2 for the wires those matrices never read — and still a VALID key: the GPU proof equals the toxic-waste
+    prediction (scalar multiplications by the oracle), the C restatement's proof, and passes the pairing check."""
+    from oracle import groth16_ref as og, pairing
+    from rapidsnark_old_amd import zkgen, views
+    k, npub = 13, 2
+    key = zkgen.generate(k, npub, seed=5, circuit_like=True)
+    nv = key["nVars"]
+    assert nv == 3 * (1 << k) // 4 + 5 and key["domainSize"] == 1 << k
+    w = np.asarray(key["witness"]).reshape(nv, 32)
+    boolean = (w[:, 1:].max(axis=1) == 0) & (w[:, 0] <= 1)
+    full = w[:, 16:].max(axis=1) > 0
+    assert 0.7 < boolean.mean() < 0.9 and 0.02 < full.mean() < 0.2
+    za = np.asarray(key["pointsA"]).reshape(nv, 64).max(axis=1) == 0
+    zb1 = np.asarray(key["pointsB1"]).reshape(nv, 64).max(axis=1) == 0
+    zb2 = np.asarray(key["pointsB2"]).reshape(nv, 128).max(axis=1) == 0
+    assert za.mean() > 0.25 and zb1.mean() > 0.25 and (zb1 == zb2).all() and not za.all()
+    rec = np.frombuffer(np.asarray(key["coefs"])[4:].tobytes(), dtype=synth_dtype())
+    assert (rec["v"].max(axis=1) > 0).all() and rec["s"].max() < nv
+    r, s = 0xBADC0FFEE, (1 << 240) + 31337
+    a, b, c = zkgen.expected_proof_dlogs(key, r, s)
+    pts = (bn.G1.mul(bn.G1.gen, a), bn.G2.mul(bn.G2.gen, b), bn.G1.mul(bn.G1.gen, c))
+    want = bn.g1_to_bytes(pts[0]) + bn.g2_to_bytes(pts[1]) + bn.g1_to_bytes(pts[2])
+    for precomp in (False, True):
+        p = views.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=precomp)
+        assert p.prove_host(key["witness"], r, s) == want
+        p.lib.zk_prover_destroy(p.h)
+    assert co.prove(co.ZkeyView(key), key["witness"], r, s) == want
+    vkj = zkgen.verification_key(key)
+    vk = {"alpha1": tuple(int(x) for x in vkj["vk_alpha_1"][:2]), "IC": [tuple(int(x) for x in pt[:2]) for pt in vkj["IC"]]}
+    for name in ("beta2", "gamma2", "delta2"):
+        j = vkj["vk_%s_2" % name[:-1]]
+        vk[name] = ((int(j[0][0]), int(j[0][1])), (int(j[1][0]), int(j[1][1])))
+    pub = [int.from_bytes(w[i].tobytes(), "little") for i in range(1, npub + 1)]
+    assert pairing.groth16_verify(vk, pub, pts)
+    assert og.proof_to_json(pts) == zk.proof_to_json(want)
+
+
+def synth_dtype():
+    from rapidsnark_old_amd import synth
+    return synth.COEF_DTYPE
+
+
 def test_zkgen_tool_at_2p20_with_cli(zk, tmp_path):
     """tools/zkgen.py 20 --prove: a valid key at BASELINE configs[1]'s size written to disk (~1.1 GB .zkey), proved by
     the one-shot CLI, proof.json checked against the toxic waste; the multi-GPU path proves the same file."""

@@ -138,6 +138,32 @@ def test_synthetic_family_definition(zk):
     assert synth.g1_gen_bytes() == bn.g1_to_bytes(bn.G1.gen) and synth.g2_gen_bytes() == bn.g2_to_bytes(bn.G2.gen)
 
 
+def test_circuit_shaped_member_of_the_family(zk):
+    """shape="circuit": nVars = 3/4 of the domain + 5, three public signals, ~30 % of the rows of A and of B1/B2 (the same
+    rows) at infinity — and the known-discrete-log bookkeeping still predicts the C restatement's MSM sums."""
+    import numpy as np
+    from oracle import c_oracle as co
+    from rapidsnark_old_amd import synth
+    k = 9
+    wl = synth.workload(k, co.chainp_g1, co.chainp_g2, co.g1_mul, co.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes(), shape="circuit")
+    nv = wl["nVars"]
+    assert nv == 3 * (1 << k) // 4 + 5 and wl["nPublic"] == 3 and wl["domainSize"] == 1 << k
+    assert wl["pointsA"].size == nv * 64 and wl["pointsB2"].size == nv * 128 and wl["pointsC"].size == (nv - 4) * 64
+    za, zb = wl["zero_rows"]["A"], wl["zero_rows"]["B"]
+    assert 0.2 < za.mean() < 0.4 and 0.2 < zb.mean() < 0.4 and not (za == zb).all()
+    A, B1, B2 = (np.asarray(wl[t]).reshape(nv, -1) for t in ("pointsA", "pointsB1", "pointsB2"))
+    assert (A[za] == 0).all() and (A[~za].max(axis=1) > 0).all() and (B1[zb] == 0).all() and (B2[zb] == 0).all() and (B2[~zb].max(axis=1) > 0).all()
+    rec = np.frombuffer(np.asarray(wl["coefs"])[4:].tobytes(), dtype=synth.COEF_DTYPE)
+    assert rec["s"].max() < nv and rec.size == wl["nCoefs"]
+    w = synth.make_witness(k, seed=2, kind="realistic", n_vars=nv)
+    assert w.size == nv * 32
+    sums = co.prove_msm(co.ZkeyView(wl), w)                  # zk_msm_sums: pih | pi_a | pib1 | pi_b (G2) | pi_c, affine points
+    want = synth.expected_msm_dlogs(wl, w, np.zeros(32, dtype=np.uint8))
+    G = bn.g1_to_bytes(bn.G1.gen)
+    assert sums[64:128] == co.g1_mul(G, want["pi_a"]) and sums[128:192] == co.g1_mul(G, want["pib1"])
+    assert sums[192:320] == co.g2_mul(bn.g2_to_bytes(bn.G2.gen), want["pi_b"]) and sums[320:384] == co.g1_mul(G, want["pi_c"])
+
+
 def test_parity_kit_shim_serves_r_then_s(tmp_path):
     """tools/refcheck: the LD_PRELOAD replacement of randombytes_buf hands out r on the first call and s
     on the second, 31 bytes each, as src/groth16.cpp:216-217 consumes them."""

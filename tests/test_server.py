@@ -232,14 +232,17 @@ def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch):
     import concurrent.futures
     from rapidsnark_old_amd import synth, zkgen
     k, nreq = 15, 64
-    key = zkgen.generate(k, 2, seed=3)
+    key = zkgen.generate(k, 2, seed=3, circuit_like=True)        # nVars = 3/4 n + 5, 80 % boolean signals, all-zero rows in A / B1 / B2
+    assert key["nVars"] == 3 * (1 << k) // 4 + 5
     zkgen.write_all(key, str(tmp_path))
     os.rename(tmp_path / "circuit.zkey", tmp_path / "auth.zkey")
     r, s = 0x0F1E2D3C4B5A6978, (1 << 231) + 4242
     env_rs = {"ZKHIP_FIXED_R": _le_hex(r), "ZKHIP_FIXED_S": _le_hex(s)}
-    # (ii) expected proof from the toxic waste alone
+    # (ii) expected proof from the toxic waste alone: discrete logs in Fr, then three scalar multiplications and the JSON
+    # text by the ORACLE (oracle/bn254.py, oracle/groth16_ref.py) — no curve arithmetic of the product in the expectation
+    from oracle import bn254 as obn, groth16_ref as og
     a, b, c = zkgen.expected_proof_dlogs(key, r, s)
-    want = zk.proof_to_json(zk.g1_mul(synth.g1_gen_bytes(), a) + zk.g2_mul(synth.g2_gen_bytes(), b) + zk.g1_mul(synth.g1_gen_bytes(), c))
+    want = og.proof_to_json((obn.G1.mul(obn.G1.gen, a), obn.G2.mul(obn.G2.gen, b), obn.G1.mul(obn.G1.gen, c)))
     # (i) the one-shot CLI on the same files
     cli = subprocess.run([os.path.join(ROOT, "rapidsnark-old_amd", "prover"), str(tmp_path / "auth.zkey"), str(tmp_path / "witness.wtns"),
                           str(tmp_path / "proof.json"), str(tmp_path / "public.json")], env=dict(os.environ, **env_rs), capture_output=True, text=True, timeout=300)
