@@ -643,7 +643,9 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
                     const uint4 t4 = q4[i];
                     nextP.l[4 * i] = (int32_t)t4.x; nextP.l[4 * i + 1] = (int32_t)t4.y; nextP.l[4 * i + 2] = (int32_t)t4.z; nextP.l[4 * i + 3] = (int32_t)t4.w;
                 }
-                const uint2 t2 = *reinterpret_cast<const uint2 *>(q4 + 4);
+                // (the two extra dwords come from the 8 bytes in FRONT of the row — or its own first 8 for row 0 — so that the last
+                // row of the table does not read past the allocation)
+                const uint2 t2 = *(reinterpret_cast<const uint2 *>(src) - (src != points ? 1 : 0));
                 nextP.l[16] = (int32_t)t2.x; nextP.l[17] = (int32_t)t2.y;
             }
 #else

@@ -14,6 +14,9 @@
 #include <sys/random.h>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -738,16 +741,79 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
 // calling thread returns at once and goes on enqueueing the proof (measured at 2^22: staging inside
 // the call cost 5 ms per proof — the two-in-flight overlap has to wait for the next submit).  Either
 // way the caller's buffer must stay valid and untouched until the proof has been collected.
+// The copies are done by a small persistent pool (four threads, started with the first staged witness): a std::thread per
+// segment cost ~40 us each, which is what a 4 MiB piece of a 2^20 witness takes to copy — the pieces of such a witness were
+// staged by ONE thread each and the upload of a lone 2^20 proof was bound by that memcpy (1.4 ms for 0.65 ms of DMA).
+namespace {
+struct StagePool {
+    struct Seg { uint8_t *dst; const uint8_t *src; size_t len; std::atomic<int> *left; };
+    std::mutex m;
+    std::condition_variable cv, done;
+    std::deque<Seg> q;
+    std::vector<std::thread> th;
+    bool stop = false;
+    StagePool() {
+        for (int i = 0; i < 4; i++) th.emplace_back([this] { run(); });
+    }
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void run() {
+        for (;;) {
+            Seg s;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                s = q.front();
+                q.pop_front();
+            }
+            memcpy(s.dst, s.src, s.len);
+            if (s.left->fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(m);
+                done.notify_all();
+            }
+        }
+    }
+    // copies [src, src + bytes) to dst with the pool's threads AND the calling one; returns when all of it is there
+    void copy(uint8_t *dst, const uint8_t *src, size_t bytes) {
+        const size_t nseg = bytes >= ((size_t)1 << 20) ? 5 : 1, per = (bytes / nseg + 63) & ~(size_t)63;
+        std::atomic<int> left{0};
+        size_t mine_lo = 0, mine_hi = bytes;
+        if (nseg > 1) {
+            int pushed = 0;
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t t = 1; t < nseg; t++) {
+                const size_t lo = t * per, hi = lo + per < bytes ? lo + per : bytes;
+                if (lo < hi) {
+                    q.push_back(Seg{dst + lo, src + lo, hi - lo, &left});
+                    pushed++;
+                }
+            }
+            left.store(pushed);
+            mine_hi = per < bytes ? per : bytes;
+        }
+        if (nseg > 1) cv.notify_all();
+        memcpy(dst + mine_lo, src + mine_lo, mine_hi - mine_lo);
+        if (nseg > 1) {
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return left.load() == 0; });
+        }
+    }
+};
+StagePool &stage_pool() {
+    static StagePool *pool = new StagePool();      // (never destroyed: its threads must not be joined from an exit handler)
+    return *pool;
+}
+}   // namespace
 static void stage_job_run(void *arg) {
     const StageJob *j = (const StageJob *)arg;
-    const size_t nt = j->bytes >= ((size_t)8 << 20) ? 4 : 1, per = (j->bytes / nt + 63) & ~(size_t)63;
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; t++) {
-        const size_t lo = t * per, hi = lo + per < j->bytes ? lo + per : j->bytes;
-        if (lo < hi) th.emplace_back([=] { memcpy(j->dst + lo, j->src + lo, hi - lo); });
-    }
-    memcpy(j->dst, j->src, per < j->bytes ? per : j->bytes);
-    for (auto &t : th) t.join();
+    stage_pool().copy(j->dst, j->src, j->bytes);
 }
 // the slot's HBM witness buffer and the events of its upload (host-witness proofs)
 static void ensure_witness_buffer(zk_prover *p, zk_prover::ProofSlot &q) {
@@ -777,13 +843,13 @@ static const Fr *upload_witnesses(zk_prover *p, zk_prover::ProofSlot &q, const u
         (void)hipGetLastError();                       // an unregistered pointer is reported as an error: not one
         const uint8_t *src = h_wtns[k];
         if (!pinned) {
-            if (count == 1 && bytes >= ((size_t)32 << 20) && p->in_flight == 0) {
+            if (count == 1 && bytes >= ((size_t)4 << 20) && p->in_flight == 0) {
                 // A large pageable witness (128 MiB at 2^22): pieces alternate between two upload streams, so the staging of
                 // piece i+1 (host function: four threads of memcpy) runs beside the DMA of piece i.  Staging and DMA of the whole
                 // vector one after the other were 5 ms on the critical path of a synchronous zk_prove: 39.4 -> 38.2 ms at 2^22.
                 // Only when no other proof is in flight: in a full pipeline the upload is hidden anyway and the sixteen extra
                 // stream operations cost 1 % of the period.
-                const size_t npc = 8, per = ((bytes / npc) + 4095) & ~(size_t)4095;
+                const size_t npc = bytes >= ((size_t)32 << 20) ? 8 : 4, per = ((bytes / npc) + 4095) & ~(size_t)4095;      // (pieces of >= 1 MiB)
                 // staging: the slot's full-size pinned copy when a pipelined submission has made one, else a ring of two pieces
                 // (one per stream: piece c + 2 is staged after the DMA of piece c, which stream order guarantees) — the first
                 // proof of a process (the one-shot CLI's only one) no longer waits ~20 ms for 128 MiB of pinned memory
