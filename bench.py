@@ -202,9 +202,12 @@ def run(args):
     torch.cuda.synchronize()
     pipelined = bool(args.pipeline)
 
-    def timed_run(in_hbm, steps, warmup):
+    leg_prefix = "2p%d%s" % (args.log2n, "" if args.shape == "dense" else "_" + args.shape)
+
+    def timed_run(in_hbm, steps, warmup, leg=None):
         """`warmup` untimed + exactly `steps` timed whole proofs, each with its own witness and random
-        r,s (like the reference).  -> (seconds, mean stage timings)."""
+        r,s (like the reference).  -> (seconds, mean stage timings).  leg: name of the profile leg the TIMED region
+        forms (a marker launch in front of it when ZK_BENCH_LEG_MARKERS=1; nothing in a normal run)."""
         units = args.batch if (args.batch > 1 and world == 1 and not in_hbm) else 1     # proofs per submission
         nsub = steps // units
 
@@ -252,6 +255,8 @@ def run(args):
                 submit(i)
             for i in range(depth0):
                 collect()
+        if leg:
+            leg_marker(zk, torch, leg)           # behind the warm-up and the pipeline fill: the leg holds the timed proofs only
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -337,12 +342,12 @@ def run(args):
 
     headline_hbm = args.witness_in == "hbm"
     from rapidsnark_old_amd.telemetry import ClockSampler
-    leg_marker(zk, torch, "2p%d_headline" % args.log2n)
-    with ClockSampler(local_rank) as clock:          # shader clock + socket power WHILE the headline runs (issue-bound roofline)
-        elapsed, stage = timed_run(headline_hbm, args.steps, args.warmup)
+    leg_marker(zk, torch, leg_prefix + "_warmup")
+    with ClockSampler(local_rank, enabled=os.environ.get("ZK_BENCH_CLOCK", "1") != "0") as clock:   # shader clock + socket power WHILE the headline runs (issue-bound roofline)
+        elapsed, stage = timed_run(headline_hbm, args.steps, args.warmup, leg=leg_prefix + "_headline")
     # the other witness placement, same K (outside the headline's timed region)
-    leg_marker(zk, torch, "2p%d_other_witness_placement" % args.log2n)
-    other_elapsed, other_stage = timed_run(not headline_hbm, args.steps, 1)
+    leg_marker(zk, torch, leg_prefix + "_between")
+    other_elapsed, other_stage = timed_run(not headline_hbm, args.steps, 1, leg=leg_prefix + "_other_witness_placement")
 
     def one_proof(i):
         return prover.prove_dev(wits_dev[i % len(wits_dev)].data_ptr())
@@ -375,19 +380,19 @@ def run(args):
     lone = {}
     if world == 1:                        # outside the timed region: strictly one proof at a time
         torch.cuda.synchronize()
-        leg_marker(zk, torch, "2p%d_lone_resident" % args.log2n)
+        leg_marker(zk, torch, leg_prefix + "_lone_resident")
         t1 = time.perf_counter()
         for i in range(3):
             one_proof(i)
             for kk, v in prover.timings().items():
                 lone[kk] = lone.get(kk, 0.0) + v / 3
         latency_ms = (time.perf_counter() - t1) / 3 * 1e3
-        leg_marker(zk, torch, "2p%d_lone_host_witness" % args.log2n)
+        leg_marker(zk, torch, leg_prefix + "_lone_host_witness")
         t1 = time.perf_counter()
         for i in range(3):
             prover.prove_host(wits_host[i % len(wits_host)])        # zk_prove: host witness, synchronous (main_prover.cpp:75)
         latency_host_ms = (time.perf_counter() - t1) / 3 * 1e3
-    leg_marker(zk, torch, "2p%d_after" % args.log2n)
+    leg_marker(zk, torch, leg_prefix + "_after")
     if dist:
         dist.barrier()
     if rank != 0:

@@ -589,9 +589,14 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     }
     p->nloc = p->part ? p->sh.size() : n;
     {
-        // below ~2^19 a proof is bound by the latencies of its kernels, not by their work
+        // below ~2^20 a proof is bound by the latencies of its kernels, not by their work — and so are the
+        // SHARDS of a larger one: A, B1 and C as one set of launches (level-1, merges, ONE reduction over three bucket
+        // sets).  Same box, probes build (profiles/r04e_shard8_experiments.txt, r04f_batch_abc_experiments.txt): rank-0 share of
+        // 8 shards of 2^22 7.22 -> 6.48 ms one at a time / 6.39 -> 6.10 two in flight, 4 shards 13.8 -> 11.5 / 10.9 -> 10.3,
+        // 2 shards 20.7 -> 20.5 / 19.5 -> 18.5, 8 shards of 2^24 20.7 -> 20.3 / 19.4 -> 18.6; unsharded 2^19 5.06 -> 4.86 ms
+        // (host witnesses; 2^20: 9.09 -> 9.07, left off).
         const char *e = getenv("ZKHIP_BATCH_ABC");
-        p->batch_abc = e ? atoi(e) != 0 : p->sv.size() < (1u << 19);
+        p->batch_abc = e ? atoi(e) != 0 : (p->sv.size() < (1u << 20) || (p->shard_count > 1 && p->sv.size() <= (1u << 21)));
     }
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_out, hipEventDisableTiming));

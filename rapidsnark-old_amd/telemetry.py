@@ -52,12 +52,15 @@ class ClockSampler:
     """with ClockSampler(device) as cs: ... ; cs.summary() -> {"clock_ghz", "power_w", "samples", "source"} (None values when
     the box offers no telemetry)."""
 
-    def __init__(self, device=0, period_s=0.05):
+    def __init__(self, device=0, period_s=0.05, enabled=True):
         self.device, self.period_s = device, period_s
         self.mhz, self.watts = [], []
         self._stop = threading.Event()
         self._th = None
         self.source = None
+        self._smi = self._h = None
+        if not enabled:
+            return
         try:
             self._smi, self._h = _amdsmi_handle(device)
             self.source = "amdsmi (gpu_metrics current_gfxclks / clock_info GFX), sampled every %d ms during the timed region" % int(period_s * 1e3)
