@@ -389,9 +389,10 @@ def run(args):
         latency_ms = (time.perf_counter() - t1) / 3 * 1e3
         leg_marker(zk, torch, leg_prefix + "_lone_host_witness")
         t1 = time.perf_counter()
-        for i in range(3):
+        nsync = 8                       # (three were too few: the mean moved by +-1 ms between runs of one box)
+        for i in range(nsync):
             prover.prove_host(wits_host[i % len(wits_host)])        # zk_prove: host witness, synchronous (main_prover.cpp:75)
-        latency_host_ms = (time.perf_counter() - t1) / 3 * 1e3
+        latency_host_ms = (time.perf_counter() - t1) / nsync * 1e3
     leg_marker(zk, torch, leg_prefix + "_after")
     if dist:
         dist.barrier()
@@ -419,6 +420,8 @@ def run(args):
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)",
               "witness_upload": ("each rank uploads 1/N over PCIe, all_gather over xGMI" if sliced_upload else "whole witness per rank") if world > 1 else "whole witness",
               "distinct_witnesses": "%d for %d steps + %d warm-up%s" % (len(wits_host), args.steps, args.warmup, "" if len(wits_host) >= nw else " (cycled)")}
+    batched_abc = batch_abc_default(-(-wl["nVars"] // world), world)
+    config["msm_a_b1_c_in_one_launch"] = batched_abc
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
     pts_per_launch = n / world
     alg_bytes = G1_MSM_BYTES_PER_POINT * pts_per_launch
@@ -430,7 +433,10 @@ def run(args):
                                           "instructions (46 % of a proof's) and by exclusive time (4 launches of ~3.8 ms alone out of a ~33 ms period))",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "launch_ms": round(g1_ms, 4), "launches_per_proof": 4, "algorithmic_bytes": alg_bytes,
+                "launch_ms": round(g1_ms, 4), "msms_per_proof": 4, "launches_per_proof": 2 if batched_abc else 4, "algorithmic_bytes": alg_bytes,
+                "launch_ms_definition": "time of the kernel per G1 MSM (algorithmic_bytes each): the sum of the kernel's launch durations of a proof / 4"
+                                        + (" — MSM A, B1 and C are ONE launch over three point tables (blockIdx.y; 3 x algorithmic_bytes), MSM H another: in a "
+                                           "rocprofv3 kernel table of the leg, launch_ms = TotalDurationNs of k_msm_accum_l1<Fq> / (4 x proofs of the leg)" if batched_abc else ""),
                 "launch_sharing": "launch_ms is the mean over the timed region, where a launch shares the chip with the kernels of the other proofs in flight "
                                   "(config.proofs_in_flight): more in flight raises proofs/s and LOWERS this fraction; launch_ms_one_proof_in_flight is the same "
                                   "launch with one proof at a time (it still runs beside that proof's own G2 launch), measured after the timed region",
@@ -661,6 +667,15 @@ def leg_marker(zk, torch, name):
     zk.fr_mul_vec(a, a)
     torch.cuda.synchronize()
     sys.stderr.write("[bench] leg marker %d (grid of %d workgroups): %s\n" % (len(_LEGS), 16 + len(_LEGS), name))
+
+
+def batch_abc_default(witness_entries_per_prover, world):
+    """Mirror of the library's rule (csrc/prover.hip, zk_prover_create): MSM A, B1 and C as one set of launches unless the
+    prover is unsharded and holds 2^20 .. 2^22 - 1 witness entries; ZKHIP_BATCH_ABC overrides."""
+    e = os.environ.get("ZKHIP_BATCH_ABC")
+    if e is not None:
+        return e != "0"
+    return not (world == 1 and (1 << 20) <= witness_entries_per_prover < (1 << 22))
 
 
 def plan_window_bits(n, world, precomp):

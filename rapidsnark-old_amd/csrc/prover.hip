@@ -593,10 +593,15 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         // SHARDS of a larger one: A, B1 and C as one set of launches (level-1, merges, ONE reduction over three bucket
         // sets).  Same box, probes build (profiles/r04e_shard8_experiments.txt, r04f_batch_abc_experiments.txt): rank-0 share of
         // 8 shards of 2^22 7.22 -> 6.48 ms one at a time / 6.39 -> 6.10 two in flight, 4 shards 13.8 -> 11.5 / 10.9 -> 10.3,
-        // 2 shards 20.7 -> 20.5 / 19.5 -> 18.5, 8 shards of 2^24 20.7 -> 20.3 / 19.4 -> 18.6; unsharded 2^19 5.06 -> 4.86 ms
-        // (host witnesses; 2^20: 9.09 -> 9.07, left off).
+        // 2 shards 20.7 -> 20.5 / 19.5 -> 18.5, 8 shards of 2^24 20.7 -> 20.3 / 19.4 -> 18.6; unsharded 2^19 5.06 -> 4.86 ms.
+        // And the LARGE unsharded circuits too (profiles/r04h_ab_batch_abc_unsharded.txt, r04i_ab_batch_abc_sync_2p22.txt, three
+        // alternations each): 2^22 period with resident witnesses 32.9 -> 32.4 ms (-1.4 %), one synchronous zk_prove 37.6 ->
+        // 37.0; 2^24 131.9 -> 130.1; tables as in the zkey 38.7 -> 37.6; circuit-shaped key with a realistic witness one at a
+        // time 13.9 -> 12.7.  Only 2^20 and 2^21 unsharded measured neutral on the period and 0.3-0.5 ms WORSE for a lone proof
+        // (three level-1 launches of 1-2 ms interleave with the other stream's work, one of 3-6 ms does not): off there.
         const char *e = getenv("ZKHIP_BATCH_ABC");
-        p->batch_abc = e ? atoi(e) != 0 : (p->sv.size() < (1u << 20) || (p->shard_count > 1 && p->sv.size() <= (1u << 21)));
+        const bool mid_size_unsharded = p->shard_count == 1 && p->sv.size() >= (1u << 20) && p->sv.size() < (1u << 22);
+        p->batch_abc = e ? atoi(e) != 0 : !mid_size_unsharded;
     }
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_out, hipEventDisableTiming));

@@ -2,9 +2,16 @@
 # Every number DESIGN.md quotes for a round, from ONE box:  tools/round_numbers.sh <tag>
 tag=$1
 out=gpurun_out/$tag/profiles
-tools/profile_bench.sh $tag > gpurun_out/${tag}_profile.log 2>&1        # the driver's command: python bench.py (2^22 + the 2^20 leg + CPU leg)
+tools/profile_bench.sh $tag > gpurun_out/${tag}_profile.log 2>&1        # the driver's command: python bench.py (2^22 + the circuit-shaped leg + the 2^20 leg + CPU leg)
+for k in 22 20; do                                                      # ONE synchronous proof as a timeline
+  rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/${tag}_lone$k -o t -- python tools/lone_proof.py $k 4 > gpurun_out/${tag}_lone$k.log 2>&1
+  python tools/lone_timeline.py gpurun_out/${tag}_lone$k 100 > $out/${tag}_lone_proof_timeline_2p$k.txt 2>&1
+  grep "^lone" gpurun_out/${tag}_lone$k.log >> $out/${tag}_lone_proof_timeline_2p$k.txt
+  rm -rf gpurun_out/${tag}_lone$k
+done
 python bench.py --log2n 20 --no-2p20 > $out/${tag}_bench_2p20.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu --witness realistic > $out/${tag}_bench_2p22_realistic.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu --witness realistic --shape circuit > $out/${tag}_bench_2p22_circuit_realistic.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu --precomp 0 > $out/${tag}_bench_2p22_plain.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu --witness-in hbm > $out/${tag}_bench_2p22_resident.json 2>/dev/null
 python bench.py --steps 8 --warmup 2 --no-cpu --log2n 24 > $out/${tag}_bench_2p24.json 2>/dev/null
