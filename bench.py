@@ -411,7 +411,7 @@ def run(args):
     # accumulation of MSM B2 (160 B per point).
     shape_txt = ("domainSize=nVars=2^%d, nPublic=1" % k) if args.shape == "dense" else \
         ("domainSize=2^%d, nVars=%d, nPublic=%d, ~30%% of the rows of A and of B1/B2 at infinity" % (k, wl["nVars"], wl["nPublic"]))
-    config = {"workload": "synthetic BN254 zkey, 2^%d constraints (%s, nCoefs=%d), %s witness" % (k, shape_txt, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80%% {0,1}, 15%% <2^32, 5%% full)"),
+    config = {"workload": "synthetic BN254 zkey, 2^%d constraints (%s, nCoefs=%d), %s witness" % (k, shape_txt, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80% {0,1}, 15% <2^32, 5% full)"),
               "shape": args.shape,
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
               "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
