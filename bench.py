@@ -550,7 +550,12 @@ def traffic_from_profiles(args, config, world, which):
                     is_g2 = "k_msm_accum_l1_g2s" in name or ("k_msm_accum_l1" in name and "Fp2T" in name)
                     is_g1 = "k_msm_accum_l1" in name and not is_g2
                     if (which == "g2" and is_g2) or (which == "g1" and is_g1):
-                        return v["hbm_bytes_raw"], "replayed from %s (separate rocprofv3 --pmc passes; raw FETCH_SIZE + WRITE_SIZE per launch)" % os.path.relpath(path, ROOT)
+                        raw, how = v["hbm_bytes_raw"], "per launch"
+                        if is_g1 and bc.get("msm_a_b1_c_in_one_launch"):
+                            # that run launched the kernel twice per proof — once over the three tables of MSM A, B1, C, once for
+                            # MSM H — so the mean per LAUNCH is two MSMs' worth: per MSM (the unit of algorithmic_bytes) = x 2 / 4
+                            raw, how = int(raw * 2 / 4), "per G1 MSM (mean per launch x 2 launches / 4 MSMs: A, B1, C share one launch)"
+                        return raw, "replayed from %s (separate rocprofv3 --pmc passes; raw FETCH_SIZE + WRITE_SIZE %s)" % (os.path.relpath(path, ROOT), how)
         except (OSError, ValueError, KeyError):
             continue
     return None, "no counter pass committed for this configuration"
