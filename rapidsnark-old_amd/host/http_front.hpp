@@ -38,7 +38,7 @@ struct Response {
 };
 typedef std::function<Response(Request &&)> Handler;      // called on a worker thread; may throw (-> 500)
 
-static const int64_t kRequestDeadlineMs = 60000;   // first byte of a request -> its last byte
+static const int64_t kRequestDeadlineMs = 120000;  // first byte of a request -> its last byte (a 128 MB body at 1 MB/s and up)
 static const int64_t kIdleMs = 30000;              // kept-alive connection with nothing in flight
 static const int64_t kDrainMs = 1000;              // reading and dropping what a refused client still sends
 static const size_t kMaxHeader = 65536;
