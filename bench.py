@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--shape", choices=["dense", "circuit"], default="dense",
                     help="dense = BASELINE's family (nVars = domainSize, every table row a point); circuit = nVars = 3/4 of the domain + 5, "
                          "3 public signals, ~30%% of the rows of A and of B1/B2 at infinity (rapidsnark_old_amd.synth)")
+    ap.add_argument("--sparse-witness", type=int, default=-1,
+                    help="1 = ZK_FLAG_SPARSE_WITNESS: 16-bit window for the four witness MSMs (what a deployment for circom circuits sets); "
+                         "default: 1 with --witness realistic, else 0")
     ap.add_argument("--no-realistic", action="store_true", help="skip the also_realistic leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--precomp", type=int, default=1,
                     help="1 (default) = window-precomputed point tables resident in HBM (ZK_FLAG_PRECOMP: one-off work in create, like\n"
@@ -162,9 +165,10 @@ def run(args):
     partitioned = world in (2, 4, 8) and args.chain != "replicated" and k >= 6
     if args.chain == "partitioned" and not partitioned:
         raise SystemExit("--chain partitioned needs 2, 4 or 8 ranks")
+    sparse = bool(args.sparse_witness) if args.sparse_witness >= 0 else (args.witness == "realistic" and bool(args.precomp) and not args.window_bits)
     prover = ProverFromView(zk, wl, device=local_rank, shard_index=rank, shard_count=world,
                             window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned,
-                            batch=args.batch if world == 1 else 0)
+                            batch=args.batch if world == 1 else 0, sparse_witness=sparse)
     t_create = time.time() - t0
     chain = None
     sliced_upload = False
@@ -414,7 +418,7 @@ def run(args):
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (%s, nCoefs=%d), %s witness" % (k, shape_txt, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80% {0,1}, 15% <2^32, 5% full)"),
               "shape": args.shape,
               "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
-              "precomputed_window_tables": bool(args.precomp), "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
+              "precomputed_window_tables": bool(args.precomp), "witness_msm_window_bits": 16 if (sparse and k > 18) else None, "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
               "witnesses_per_submission": args.batch if (args.batch > 1 and world == 1 and not headline_hbm) else 1,
               "host_threads": 2 if (pipelined and world == 1 and args.collector_thread) else 1,
               "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)",

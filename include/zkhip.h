@@ -68,6 +68,13 @@ typedef struct zk_opts {
 #define ZK_FLAG_PRECOMP 2u   /* window-precomputed point tables: W x the table memory in HBM and a longer
                               * zk_prover_create, ~19 % fewer point additions per proof (same results) */
 
+#define ZK_FLAG_SPARSE_WITNESS 8u   /* with ZK_FLAG_PRECOMP: the four witness MSMs (A, B1, B2, C; src/groth16.cpp:180-204) use a
+                              * 16-bit window (2^15 buckets per set) instead of the size-based one (2^19 at 2^22 constraints).
+                              * For CIRCUIT witnesses — mostly 0, 1 and small values: few non-zero digits — the additions are few
+                              * and the bucket reductions, which do not shrink with the witness, dominate those MSMs; with
+                              * uniformly random scalars (the benchmark's worst case) it costs three more additions per point.
+                              * Same proofs either way.  MSM H (scalars a.b - c: always full-size) keeps its window. */
+
 /* Same bytes as Proof<Engine>{A,B,C} (src/groth16.hpp:13-24): affine, Montgomery LE. */
 typedef struct zk_proof {
     uint8_t A[64];

@@ -571,7 +571,8 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             side.err = std::current_exception();
         }
     });
-    p->wbits = wbits;
+    // window of the witness MSMs (sort(w), tables A / B1 / B2 / C); MSM H keeps `wbits` (its scalars are always full-size)
+    p->wbits = (wbits == 0 && (p->flags & ZK_FLAG_SPARSE_WITNESS) && (p->flags & ZK_FLAG_PRECOMP) && p->logn > 18) ? 16u : wbits;
     hipStream_t s = p->stream;
     clk.lap("device + first stream", s);
     StreamUploader up(s);

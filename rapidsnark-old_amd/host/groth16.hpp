@@ -146,6 +146,10 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     // proofs).  Default: off for the one-shot CLI, on for the server where create is amortised.
     const char *pc = getenv("ZKHIP_PRECOMP");
     if (pc ? (pc[0] == '1') : precompDefault) o.flags |= ZK_FLAG_PRECOMP;
+    // ZKHIP_SPARSE_WITNESS=1 (with precomputed tables): 16-bit window for the four witness MSMs — for deployments whose witnesses
+    // are circuit witnesses (mostly 0, 1 and small values), ZK_FLAG_SPARSE_WITNESS in include/zkhip.h
+    if (const char *sw = getenv("ZKHIP_SPARSE_WITNESS"))
+        if (sw[0] == '1') o.flags |= ZK_FLAG_SPARSE_WITNESS;
     if (device >= 0) o.device = device;
     else if (const char *dev = getenv("ZKHIP_DEVICE")) o.device = atoi(dev);
     // ZKHIP_DEVICES=0,1,...,7: ONE proof over several GPUs of the node — every MSM table sharded by point

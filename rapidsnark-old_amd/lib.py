@@ -45,6 +45,7 @@ class zk_msm_sums(C.Structure):
 ZK_FLAG_TIMINGS = 1
 ZK_FLAG_PRECOMP = 2
 ZK_FLAG_PARTITIONED_CHAIN = 4
+ZK_FLAG_SPARSE_WITNESS = 8
 ZK_STEP_CROSS_INVERSE, ZK_STEP_LOCAL, ZK_STEP_CROSS_FORWARD, ZK_STEP_FINISH = 1, 2, 3, 4
 ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel", "wtns_h2d"]
 

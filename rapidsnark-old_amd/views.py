@@ -51,7 +51,8 @@ class MultiProverFromView:
 class ProverFromView:
     """zk.Prover over an in-memory view (numpy arrays) instead of a .zkey file."""
 
-    def __init__(self, zk, wl, device, shard_index, shard_count, window_bits, timings, precomp=False, partitioned_chain=False, batch=0):
+    def __init__(self, zk, wl, device, shard_index, shard_count, window_bits, timings, precomp=False, partitioned_chain=False, batch=0,
+                 sparse_witness=False):
         import ctypes as C
         from rapidsnark_old_amd import lib as L
         self.L = L
@@ -59,7 +60,7 @@ class ProverFromView:
         v, self.keep = view_from_workload(L, wl)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
                       (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
-                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0), batch)
+                      | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0) | (L.ZK_FLAG_SPARSE_WITNESS if sparse_witness else 0), batch)
         self.h = C.c_void_p()
         L.check(self.lib.zk_prover_create(C.byref(self.h), C.byref(v), C.byref(o)))
         self.keep = []

@@ -103,10 +103,11 @@ def test_cli_over_several_devices(tmp_path, devices):
 _DOCUMENTED = [{"ZKHIP_VERBOSE": "1"}, {"ZKHIP_SERIAL": "1"}, {"ZKHIP_PRECOMP": "1"}, {"ZKHIP_PRECOMP": "0"}, {"ZKHIP_DEVICE": "0"},
                {"ZKHIP_LANES": "1"}, {"ZKHIP_LANES": "3", "ZKHIP_LANE_STREAMS": "1"}, {"ZKHIP_TAIL": "0"}, {"ZKHIP_TAIL": "2"},
                {"ZKHIP_GRAPH": "1"}, {"ZKHIP_BATCH_ABC": "0"}, {"ZKHIP_BATCH_ABC": "1", "ZKHIP_PRECOMP": "1"},
-               {"ZKHIP_DEVICES": "0,0,0,0", "ZKHIP_REPLICATED_CHAIN": "1"}, {"GPU_MAX_HW_QUEUES": "8"}, {"ZKHIP_CLEAN_EXIT": "1"}]
+               {"ZKHIP_DEVICES": "0,0,0,0", "ZKHIP_REPLICATED_CHAIN": "1"}, {"GPU_MAX_HW_QUEUES": "8"}, {"ZKHIP_CLEAN_EXIT": "1"},
+               {"ZKHIP_SPARSE_WITNESS": "1", "ZKHIP_PRECOMP": "1"}]
 _RETIRED_PROBES = {"ZKHIP_GATHER_MASK": "0xff", "ZKHIP_ACC_ROUND_WGS": "1", "ZKHIP_ACC_CHUNK_MIN": "4", "ZKHIP_ACC_CHUNK_MAX": "8",
                    "ZKHIP_STAGE_SYNC": "1", "ZKHIP_NTT_THREADS": "512", "ZKHIP_NTT_TILE": "8", "ZKHIP_REDUCE_BITS": "0",
-                   "ZKHIP_REDUCE_CHUNK": "2", "ZKHIP_S1_PRIO": "1"}
+                   "ZKHIP_REDUCE_CHUNK": "2", "ZKHIP_S1_PRIO": "1", "ZKHIP_LONE_ORDER": "1"}
 
 
 @pytest.mark.gpu

@@ -264,3 +264,29 @@ def test_circuit_shaped_key_bit_exact_vs_c_oracle(zk, precomp):
     assert p.prove_dev(wd.data_ptr(), r, s) == ref
     assert p.prove_host(w, r, s) == ref
     p.lib.zk_prover_destroy(p.h)
+
+
+def test_sparse_witness_flag_changes_the_window_not_the_sums(zk):
+    """ZK_FLAG_SPARSE_WITNESS: the four witness MSMs on a 16-bit window (sixteen table rows per point instead of fourteen at
+    2^19, a sixteenth of the buckets) — more table memory, the same five MSM sums for a circuit-like witness and for a
+    uniformly random one; MSM H keeps its window."""
+    import torch
+    from rapidsnark_old_amd import synth, views
+    k = 19
+    wl = _gpu_workload(zk, k)
+    used = []
+    sums = {}
+    for sparse in (False, True):
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        p = views.ProverFromView(zk, wl, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=True, sparse_witness=sparse)
+        torch.cuda.synchronize()
+        used.append(free0 - torch.cuda.mem_get_info()[0])
+        for kind in ("realistic", "uniform"):
+            w = synth.make_witness(k, seed=4, kind=kind)
+            wd = torch.from_numpy(w).to("cuda:0")
+            sums[(sparse, kind)] = p.prove_msm_dev(wd.data_ptr())
+        p.lib.zk_prover_destroy(p.h)
+    assert sums[(True, "realistic")] == sums[(False, "realistic")] and sums[(True, "uniform")] == sums[(False, "uniform")]
+    assert sums[(True, "realistic")] != sums[(True, "uniform")]
+    assert used[1] > used[0] * 1.02, used          # 16 rows per point for A, B1, B2, C instead of 14 (the bucket arrays shrink: +3.6 % in all)
