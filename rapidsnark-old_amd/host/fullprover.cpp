@@ -1,5 +1,6 @@
 #include "fullprover.hpp"
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -92,6 +93,8 @@ static size_t depthFor(uint32_t domainSize) {
 FullProver::FullProver(std::string zkeyFileNames[], int size) {
     workerDevices = workerDevicesFromEnv();
     if (const char *q = getenv("ZKHIP_QUEUE")) queueCap = (size_t)strtoul(q, nullptr, 10);
+    keepResults = std::max<size_t>(4096, 4 * queueCap);
+    if (const char *kr = getenv("ZKHIP_KEEP_RESULTS")) keepResults = std::max<size_t>(1, (size_t)strtoul(kr, nullptr, 10));
     for (int i = 0; i < size; i++) {
         const std::string circuit = std::filesystem::path(zkeyFileNames[i]).stem().string();   // circuit name = file stem (fullprover.cpp:14-19,25)
         auto zkey = BinFileUtils::openExisting(zkeyFileNames[i], "zkey", 1);
@@ -332,7 +335,13 @@ bool FullProver::enqueueWitness(std::string wtnsImage, std::string circuit, uint
 
 void FullProver::remember(const JobPtr &job) {
     jobs[job->id] = job;
-    while (jobs.size() > 4096) jobs.erase(jobs.begin());
+    // Results wait here for their owner's GET /status/<id>.  Only FINISHED jobs are ever dropped, oldest first, once more than
+    // keepResults jobs are known: the first version dropped the 4096th-oldest job whatever its state — a client that submitted
+    // 8192 requests before polling found half of them "unknown" while they were still queued (tools/soak.py's server run).
+    for (auto it = jobs.begin(); jobs.size() > keepResults && it != jobs.end();) {
+        if (it->second->status != busy) it = jobs.erase(it);
+        else ++it;
+    }
 }
 
 std::string FullProver::getStatus(uint64_t id) {

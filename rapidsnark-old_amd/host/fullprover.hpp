@@ -82,7 +82,8 @@ private:
     std::deque<JobPtr> incoming, readyJobs;
     size_t inWitness = 0;                      // jobs inside a witness generator right now (count against queueCap)
     uint64_t abortEpoch = 0;                   // POST /cancel: jobs accepted before it that have not reached a GPU are dropped
-    std::map<uint64_t, JobPtr> jobs;           // recent jobs by id (bounded)
+    std::map<uint64_t, JobPtr> jobs;           // jobs by id: every unfinished one + the most recent `keepResults` finished ones
+    size_t keepResults = 4096;                 // ZKHIP_KEEP_RESULTS (default: 4096, or four queues' worth)
     std::vector<std::thread> threads;
 
     void generateWitness(Job &job, const std::string &tag);   // throws; fills job.wtns / wtnsData / pubData

@@ -221,6 +221,36 @@ def test_queue_full_is_503(tmp_path):
 
 
 @pytest.mark.gpu
+def test_results_are_kept_for_their_owner_and_unfinished_jobs_are_never_dropped(tmp_path):
+    """Throughput mode remembers jobs for GET /status/<id>: the most recent ZKHIP_KEEP_RESULTS FINISHED ones, and every job that
+    is still waiting or running.  (The first version dropped the oldest job once 4096 were known, whatever its state: a client that
+    submitted 8192 requests before it polled found half of them "unknown".)  Here: one witness thread, a 50 ms generator, a result
+    memory of TWO — twelve jobs submitted at once are all "busy" or "success" when polled straight away, never unknown; once all
+    are done, the two newest are still there and the oldest has made room."""
+    srv, port = _start_server(tmp_path, ["r1cs_n8"], {"ZKHIP_QUEUE": "16", "ZKHIP_WITNESS_THREADS": "1", "ZKHIP_KEEP_RESULTS": "2", "ZKHIP_WORKERS": "0"})
+    try:
+        jobs = []
+        for _ in range(12):
+            code, body, _ = _http(port, "POST", "/input/r1cs_n8", b"{}")
+            assert code == 200
+            jobs.append(json.loads(body)["job"])
+        first = [json.loads(_http(port, "GET", "/status/%d" % j)[1]) for j in jobs]
+        assert all(d["status"] in ("busy", "success") for d in first[2:]), first      # (jobs 1-2 may already be finished AND replaced)
+        assert sum(d["status"] == "busy" for d in first) >= 6
+        for _ in range(2000):                                   # until the newest one is done
+            if json.loads(_http(port, "GET", "/status/%d" % jobs[-1])[1])["status"] != "busy":
+                break
+            time.sleep(0.01)
+        last = [json.loads(_http(port, "GET", "/status/%d" % j)[1]) for j in jobs]
+        assert last[-1]["status"] == "success" and last[-2]["status"] == "success"
+        assert last[0] == {"error": "unknown job", "status": "failed"}
+        assert all(d["status"] != "busy" for d in last)
+    finally:
+        srv.terminate()
+        srv.wait(10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("batch", ["1", "4"])
 def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch):
     """BASELINE configs[4] on a key of its size class: no Semaphore / iden3-auth zkey exists in the image, so the key is a
