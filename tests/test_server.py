@@ -226,7 +226,7 @@ def test_results_are_kept_for_their_owner_and_unfinished_jobs_are_never_dropped(
     is still waiting or running.  (The first version dropped the oldest job once 4096 were known, whatever its state: a client that
     submitted 8192 requests before it polled found half of them "unknown".)  Here: one witness thread, a 50 ms generator, a result
     memory of TWO — twelve jobs submitted at once are all "busy" or "success" when polled straight away, never unknown; once all
-    are done, the two newest are still there and the oldest has made room."""
+    are done every result is there, and the next job's arrival trims the memory to the newest finished one beside itself."""
     srv, port = _start_server(tmp_path, ["r1cs_n8"], {"ZKHIP_QUEUE": "16", "ZKHIP_WITNESS_THREADS": "1", "ZKHIP_KEEP_RESULTS": "2", "ZKHIP_WORKERS": "0"})
     try:
         jobs = []
@@ -242,9 +242,19 @@ def test_results_are_kept_for_their_owner_and_unfinished_jobs_are_never_dropped(
                 break
             time.sleep(0.01)
         last = [json.loads(_http(port, "GET", "/status/%d" % j)[1]) for j in jobs]
-        assert last[-1]["status"] == "success" and last[-2]["status"] == "success"
-        assert last[0] == {"error": "unknown job", "status": "failed"}
-        assert all(d["status"] != "busy" for d in last)
+        assert all(d["status"] == "success" for d in last), last          # nothing was dropped while it was unfinished
+        # the memory is trimmed when the next job arrives: finished results beyond the two newest make room, the new job stays
+        code, body, _ = _http(port, "POST", "/input/r1cs_n8", b"{}")
+        extra = json.loads(body)["job"]
+        for _ in range(2000):
+            doc = json.loads(_http(port, "GET", "/status/%d" % extra)[1])
+            if doc["status"] != "busy":
+                break
+            time.sleep(0.01)
+        assert doc["status"] == "success"
+        after = [json.loads(_http(port, "GET", "/status/%d" % j)[1]) for j in jobs]
+        assert after[0] == {"error": "unknown job", "status": "failed"} and after[-1]["status"] == "success"
+        assert sum(d["status"] == "success" for d in after) == 1
     finally:
         srv.terminate()
         srv.wait(10)
