@@ -128,3 +128,49 @@ def test_many_idle_connections_cost_nothing(server):
     assert code == 200 and dt < 0.25
     for s in idle:
         s.close()
+
+
+def test_malformed_and_hostile_requests_never_take_the_server_down(server):
+    """Random bytes, absurd Content-Length values, header floods, half-requests abandoned, connections reset in the middle of a
+    body: whatever arrives, the worker keeps answering /status (one worker thread, so a wedged or crashed parser would show)."""
+    import random
+    rng = random.Random(20260929)
+    cases = [b"\r\n\r\n", b"GET\r\n\r\n", b"GET / HTTP/1.1\r\nContent-Length: -5\r\n\r\n", b"POST /echo HTTP/1.1\r\nContent-Length: abc\r\n\r\nxyz",
+             b"POST /echo HTTP/1.1\r\nContent-Length: 18446744073709551615\r\n\r\n", b"POST /echo HTTP/1.1\r\nContent-Length: 99999999999999999999999\r\n\r\n",
+             b"POST /echo HTTP/1.1\r\nContent-Length: 3\r\nContent-Length: 4\r\n\r\nabcd", b"GET /status HTTP/1.1\r\n" + b"A: b\r\n" * 5000 + b"\r\n",
+             b"GET /status HTTP/9.9\r\n\r\n", b"\x00" * 5000 + b"\r\n\r\n", b"POST /echo HTTP/1.1\r\nTransfer-Encoding: gzip, chunked\r\n\r\n5\r\nhello\r\n0\r\n\r\n",
+             b"GET /status?" + b"x" * 70000 + b" HTTP/1.1\r\n\r\n"]
+    for _ in range(120):
+        n = rng.randrange(1, 400)
+        cases.append(bytes(rng.randrange(256) for _ in range(n)) + rng.choice([b"", b"\r\n\r\n", b"\r\n"]))
+    for i, blob in enumerate(cases):
+        s = socket.create_connection(("127.0.0.1", server), timeout=5)
+        try:
+            s.sendall(blob)
+            if i % 3 == 0:
+                s.settimeout(0.05)
+                try:
+                    s.recv(65536)
+                except (socket.timeout, ConnectionError):
+                    pass
+            if i % 5 == 0:                                  # reset instead of a clean close
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, b"\x01\x00\x00\x00\x00\x00\x00\x00")
+        except ConnectionError:
+            pass
+        finally:
+            s.close()
+        if i % 10 == 0:
+            code, body, dt = status(server)
+            assert code == 200 and body == b'{"status":"ok"}' and dt < 0.5
+    # a body cut off by a reset half-way
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    s.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 500000\r\n\r\n" + b"q" * 100000)
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, b"\x01\x00\x00\x00\x00\x00\x00\x00")
+    s.close()
+    code, body, _ = status(server)
+    assert code == 200 and body == b'{"status":"ok"}'
+    # ... and a well-formed request still gets its own answer afterwards
+    c = http.client.HTTPConnection("127.0.0.1", server, timeout=5)
+    c.request("POST", "/echo", body=b"x" * 1234)
+    r = c.getresponse()
+    assert r.status == 200 and r.read() == b"1234"
