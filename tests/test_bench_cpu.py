@@ -14,7 +14,7 @@ import bench
 
 
 def _config():
-    d = json.loads([ln for ln in open(os.path.join(ROOT, "profiles", "r04q_bench.json")) if ln.startswith("{")][-1])
+    d = json.loads([ln for ln in open(os.path.join(ROOT, "profiles", "r04z_bench.json")) if ln.startswith("{")][-1])
     return d["config"], d
 
 
@@ -44,7 +44,8 @@ def test_traffic_is_per_msm_when_a_b1_c_share_a_launch():
     args = types.SimpleNamespace(traffic_bytes=None)
     g1, src = bench.traffic_from_profiles(args, config, 1, "g1")
     g2, _ = bench.traffic_from_profiles(args, config, 1, "g2")
-    raw = json.load(open(os.path.join(ROOT, "profiles", "r04q_pmc_traffic.json")))
+    import re
+    raw = json.load(open(os.path.join(ROOT, re.search(r"profiles/\w+_pmc_traffic\.json", src).group(0))))      # the file the line says it replays
     per_launch = [v["hbm_bytes_raw"] for k, v in raw["kernels"].items() if "k_msm_accum_l1<" in k][0]
     assert raw["bench"]["config"]["msm_a_b1_c_in_one_launch"] is True
     assert g1 == int(per_launch * 2 / 4) and "per G1 MSM" in src and 4.0e9 < g1 < 5.5e9          # two launches carry four MSMs
