@@ -561,6 +561,11 @@ __device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes,
 #define ZK_GATHER_ROW(i) (i)
 #endif
 #define ACC_CHUNK_N 32u     // slots per unit at levels >= 2 used to SIZE the workspace (a G2 wave takes 32, a G1 wave 64)
+// Threads per workgroup of the level-1 kernels.  They use no LDS and no barrier, so the workgroup is only the unit in which the
+// dispatcher hands waves to a CU (ZK_L1_BLOCK=64 in a measurement build: one wave per workgroup).
+#ifndef ZK_L1_BLOCK
+#define ZK_L1_BLOCK 256
+#endif
 #define SLOT_EMPTY 0xffffffffu
 #define FLAG_STARTS 1u
 #define FLAG_ENDS 2u
@@ -577,7 +582,7 @@ __device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes,
 #define ZK_G1_L1_WAVES
 #endif
 template <class F>
-__global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buckets0, const uint32_t *offsets, const uint32_t *entries,
+__global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buckets0, const uint32_t *offsets, const uint32_t *entries,
                                                       AccumBatch batch, uint32_t nbuckets_total, G1Acc *out_part0, uint32_t *out_key0,
                                                       uint32_t *out_flag0, uint32_t nlanes, uint32_t chunk_min) {
     static_assert(sizeof(F) == sizeof(Fq), "G1 only: the G2 level-1 kernel is k_msm_accum_l1_g2s");
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(256) ZK_G1_L1_WAVES void k_msm_accum_l1(G1Acc *buck
 #else
 #define ZK_G2_L1_WAVES
 #endif
-__global__ __launch_bounds__(256) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
+__global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s(G2Acc *buckets, const uint32_t *offsets, const uint32_t *entries,
                                                           const G2Affine *points, uint32_t idx_min, uint32_t idx_sub,
                                                           uint32_t nbuckets_total, G2Acc *out_part, uint32_t *out_key,
                                                           uint32_t *out_flag, uint32_t nlanes, uint32_t chunk_min) {
@@ -1244,12 +1249,12 @@ static uint64_t accum_round_lanes(uint32_t n_msm) {
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) {
-            if constexpr (sizeof(F) == sizeof(Fq2)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1_g2s, 256, 0);
-            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1<F>, 256, 0);
+            if constexpr (sizeof(F) == sizeof(Fq2)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1_g2s, ZK_L1_BLOCK, 0);
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_msm_accum_l1<F>, ZK_L1_BLOCK, 0);
         }
-        if (e != hipSuccess || wgs < 1) { (void)hipGetLastError(); wgs = sizeof(F) == sizeof(Fq2) ? 2 : 3; }
+        if (e != hipSuccess || wgs < 1) { (void)hipGetLastError(); wgs = (sizeof(F) == sizeof(Fq2) ? 2 : 3) * (256 / ZK_L1_BLOCK); }
         if (const char *o = probe_env("ZKHIP_ACC_ROUND_WGS")) wgs = atoi(o) > 0 ? atoi(o) : wgs;   // workgroups per CU (probe)
-        return (uint64_t)wgs * 256u * (uint64_t)cus;
+        return (uint64_t)wgs * (uint64_t)ZK_L1_BLOCK * (uint64_t)cus;
     }();
     uint64_t lanes = threads / LaneModel<F>::LPE / (n_msm ? n_msm : 1);
     return lanes ? lanes : 1;
@@ -1287,11 +1292,11 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
     uint64_t lanes = accum_lanes_for<F>(max_entries, nb);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
-        hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + 255) / 256)), dim3(256), 0, s, buckets, offsets, entries,
+        hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK)), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,
                            reinterpret_cast<const G2Affine *>(batch.points[0]), batch.idx_min[0], batch.idx_sub[0], total_buckets, ws_part, ws_key, ws_flag,
                            (uint32_t)lanes, accum_chunk_min());
     } else {
-        hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + 255) / 256), nb), dim3(256), 0, s, buckets, offsets, entries,
+        hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK), nb), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,
                            batch, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes, accum_chunk_min());
     }
     if (ev) ZK_HIP(hipEventRecord(ev[1], s));
