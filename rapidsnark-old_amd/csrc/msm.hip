@@ -566,6 +566,9 @@ __device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes,
 #ifndef ZK_L1_BLOCK
 #define ZK_L1_BLOCK 256
 #endif
+#ifndef ZK_L1_PREFETCH
+#define ZK_L1_PREFETCH 1      // raw points in flight per lane in the G1 level-1 kernel
+#endif
 #define SLOT_EMPTY 0xffffffffu
 #define FLAG_STARTS 1u
 #define FLAG_ENDS 2u
@@ -617,14 +620,7 @@ __global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G1_L1_WAVES void k_msm_accum_l1(G1A
         bool started_before = offsets[b] < lo;
         typedef REGF FR;
         XYZZ<FR> acc = XYZZ<FR>::inf();
-#ifdef ZK_PROBE_LIMB_ROWS
-        // Measurement build (WRONG sums): what would tables resident in LIMB form buy?  Eighteen dwords are loaded per point (a
-        // 72-byte row, here read from the 64-byte-row table: the values are garbage, the loads and the instruction stream are
-        // those of a limb-form table) and used as the nine limbs of x and y as they are: no word -> limb unpacking.
-        struct { int32_t l[18]; } nextP;
-#else
         Affine<F> nextP;                 // raw words: the next point is in flight while this one is added
-#endif
         bool nextNeg = false, nextSkip = false;
         // two loads deep: the ENTRY of position e+2 is in flight while the POINT of e+1 is, so the address of a point
         // load never waits for its entry (a wave's three resident siblings run in phase with it — same work, same
@@ -640,40 +636,36 @@ __global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G1_L1_WAVES void k_msm_accum_l1(G1A
             nextSkip = idx < idx_min;
             bend2 = offsets[b + 2 < nbuckets_total ? b + 2 : nbuckets_total];
             const Affine<F> *src = points + (nextSkip ? 0 : ZK_GATHER_ROW(idx - idx_sub));
-#ifdef ZK_PROBE_LIMB_ROWS
-            {
-                const uint4 *q4 = reinterpret_cast<const uint4 *>(src);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint4 t4 = q4[i];
-                    nextP.l[4 * i] = (int32_t)t4.x; nextP.l[4 * i + 1] = (int32_t)t4.y; nextP.l[4 * i + 2] = (int32_t)t4.z; nextP.l[4 * i + 3] = (int32_t)t4.w;
-                }
-                // (the two extra dwords come from the 8 bytes in FRONT of the row — or its own first 8 for row 0 — so that the last
-                // row of the table does not read past the allocation)
-                const uint2 t2 = *(reinterpret_cast<const uint2 *>(src) - (src != points ? 1 : 0));
-                nextP.l[16] = (int32_t)t2.x; nextP.l[17] = (int32_t)t2.y;
-            }
-#else
             nextP.x = load_el(&src->x);
             nextP.y = load_el(&src->y);
-#endif
             entNext = entries[pos + 1 < hi ? pos + 1 : hi - 1];
         };
         uint32_t e = lo;
         fetch(e);
+#if ZK_L1_PREFETCH >= 2
+        // TWO points in flight: the table rows are random 64-byte gathers from a 3 GiB table, and with the rows confined to an
+        // L2-resident range (probe: ZKHIP_GATHER_MASK) the launch is 10 % shorter — more than the 8 % the s_waitcnt counters
+        // showed: one addition (~4.5 us) is not always enough to cover a gather under this load.  The kernel has 36 VGPRs to
+        // spare below the three-waves-per-SIMD limit; the second raw point costs 16 of them and 18 moves per addition.
+        Affine<F> curP = nextP;
+        bool curNeg = nextNeg, curSkip = nextSkip;
+        fetch(lo + 1 < hi ? lo + 1 : hi - 1);
+#endif
         while (e < hi) {
-            auto Pw = nextP;
+#if ZK_L1_PREFETCH >= 2
+            Affine<F> Pw = curP;
+            bool ng = curNeg, skip = curSkip;
+            curP = nextP; curNeg = nextNeg; curSkip = nextSkip;      // the point of position e + 1 (still on its way, normally)
+            e++;
+            fetch(e + 1 < hi ? e + 1 : hi - 1);                        // point of e + 1 (entry prefetched), entry of e + 2
+#else
+            Affine<F> Pw = nextP;
             bool ng = nextNeg, skip = nextSkip;
             e++;
             fetch(e < hi ? e : hi - 1);
-            if (!skip) {
-#ifdef ZK_PROBE_LIMB_ROWS
-                Affine<FR> P;
-#pragma unroll
-                for (int i = 0; i < 9; i++) { P.x.l[i] = Pw.l[i]; P.y.l[i] = Pw.l[9 + i]; }
-#else
-                Affine<FR> P = to_reg_affine<F>(Pw);
 #endif
+            if (!skip) {
+                Affine<FR> P = to_reg_affine<F>(Pw);
                 if (ng) negate_y(P);
                 madd(acc, P);          // curve29.hpp: bound-tracked specialisation
             }
