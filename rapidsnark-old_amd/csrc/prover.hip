@@ -23,6 +23,7 @@
 #include <memory>
 #include <stdexcept>
 #include <exception>
+#include <functional>
 
 #include "../../include/zkhip.h"
 #include "common.hpp"
@@ -717,9 +718,12 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->abc_use = p->abc.p;
     p->xb_use = p->xb.p;
     {
-        // lanes for small circuits (see zk_prover::LaneExtra).  ZKHIP_LANES=1..4 overrides.
+        // lanes for small circuits (see zk_prover::LaneExtra).  ZKHIP_LANES=1..8 overrides.  Eight up to 2^16 with one witness
+        // per submission: a proof of that size is two chains of ~28 launches whose kernels fill a fraction of the chip each, and
+        // what bounds it is how many chains run side by side (profiles/r04aj_lanes.txt: 0.72 -> 0.64 ms at 2^14, 1.16 -> 1.08 at
+        // 2^16, nothing from 2^18 on; batched submissions are SLOWER with eight: 0.39 -> 0.62 ms at 2^14 x 4).
         const char *e = getenv("ZKHIP_LANES");
-        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 22) ? 4 : 1);
+        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 16) && p->batch == 1 ? 8 : p->domainSize <= (1u << 22) ? 4 : 1);
         if (lanes < 1) lanes = 1;
         if (lanes > zk_prover::MAX_LANES) lanes = zk_prover::MAX_LANES;
         if (p->part || getenv("ZKHIP_SERIAL")) lanes = 1;
@@ -819,6 +823,71 @@ struct StagePool {
 };
 StagePool &stage_pool() {
     static StagePool *pool = new StagePool();      // (never destroyed: its threads must not be joined from an exit handler)
+    return *pool;
+}
+}   // namespace
+// The host tails of the proofs of ONE batched submission are independent (0.3 ms each: the scalar multiplications of the
+// final assembly) — and a collector that ran them one after the other was what bounded a 2^14 / 2^15 circuit: eight proofs per
+// submission = 2.4 ms of tail for 1.6 ms of GPU work.  A few persistent threads shared by every prover of the process; the
+// calling thread takes its share, so a machine with no spare core still makes progress.
+namespace {
+struct TailPool {
+    struct Job { const std::function<void(uint32_t)> *fn; std::atomic<uint32_t> next{0}, done{0}; uint32_t count = 0; };
+    std::mutex m;
+    std::condition_variable cv, fin;
+    std::deque<std::shared_ptr<Job>> q;
+    std::vector<std::thread> th;
+    TailPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned n = hw > 8 ? 7 : (hw > 1 ? hw - 1 : 0);
+        for (unsigned i = 0; i < n; i++) th.emplace_back([this] { run(); });
+    }
+    static void work(Job &j) {
+        for (;;) {
+            const uint32_t k = j.next.fetch_add(1);
+            if (k >= j.count) return;
+            (*j.fn)(k);
+            j.done.fetch_add(1);
+        }
+    }
+    void run() {
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return !q.empty(); });
+                j = q.front();
+                if (j->next.load() >= j->count) { q.pop_front(); continue; }
+            }
+            work(*j);
+            std::lock_guard<std::mutex> lk(m);
+            fin.notify_all();
+        }
+    }
+    // fn(0) .. fn(count - 1), each exactly once, on the pool's threads and the calling one; returns when all have returned.
+    // fn must not throw.
+    void for_each(uint32_t count, const std::function<void(uint32_t)> &fn) {
+        if (count <= 1 || th.empty()) {
+            for (uint32_t k = 0; k < count; k++) fn(k);
+            return;
+        }
+        auto j = std::make_shared<Job>();
+        j->fn = &fn;
+        j->count = count;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            q.push_back(j);
+        }
+        cv.notify_all();
+        work(*j);
+        std::unique_lock<std::mutex> lk(m);
+        fin.wait(lk, [&] { return j->done.load() == count; });
+        for (auto it = q.begin(); it != q.end(); ++it)
+            if (*it == j) { q.erase(it); break; }
+    }
+};
+TailPool &tail_pool() {
+    static TailPool *pool = new TailPool();        // (never destroyed, like the staging pool)
     return *pool;
 }
 }   // namespace
@@ -1384,14 +1453,20 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     if (direct && p->batch > 1) {
         // one bucket set per proof of the submission: records [msm][proof][rc]  (count checked before the wait)
         const size_t Rw = (size_t)rcw * sizeof(G1XYZZ), Rh = (size_t)rch * sizeof(G1XYZZ), R2 = (size_t)rcw * sizeof(G2XYZZ);
-        for (uint32_t k = 0; k < q.count; k++) {
+        std::atomic<int> failed{0};
+        tail_pool().for_each(q.count, [&](uint32_t k) {
             const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[k] : nullptr) : direct->r32;
             const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[k] : nullptr) : direct->s32;
-            if (HostTail::finish_from_records(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2,
-                                              w1 + k * Rw, w1 + M1 + k * Rw, w1 + 2 * M1 + k * Rw, w1 + 3 * M1 + k * Rh, w2 + k * R2,
-                                              1, cw, rcw, 1, ch, rch, r32, s32, direct->out[k].A, direct->out[k].B, direct->out[k].C))
-                throw std::runtime_error("getrandom failed");
-        }
+            try {
+                if (HostTail::finish_from_records(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2,
+                                                  w1 + k * Rw, w1 + M1 + k * Rw, w1 + 2 * M1 + k * Rw, w1 + 3 * M1 + k * Rh, w2 + k * R2,
+                                                  1, cw, rcw, 1, ch, rch, r32, s32, direct->out[k].A, direct->out[k].B, direct->out[k].C))
+                    failed.store(1);
+            } catch (...) {
+                failed.store(2);
+            }
+        });
+        if (failed.load()) throw std::runtime_error(failed.load() == 1 ? "getrandom failed" : "host tail of a batched proof failed");
         return;
     }
     if (direct) {
