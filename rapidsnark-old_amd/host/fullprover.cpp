@@ -105,11 +105,13 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
         Circuit &c = circuits[circuit];
         // throughput mode, small circuits: a submission carries up to `batch` witnesses (one set of kernel launches:
         // a 2^14 proof is ~60 latency-bound kernels, four proofs in them cost little more than one).  ZKHIP_BATCH=n
-        // (0/1 = off, at most ZK_MAX_BATCH) overrides the default of 4 up to 2^17 constraints.
+        // (0/1 = off, at most ZK_MAX_BATCH) overrides the default: 8 up to 2^16 constraints, 4 at 2^17 (round 4, with the host
+        // tails of a submission running side by side: 0.39 -> 0.35 / 0.54 -> 0.48 / 0.81 -> 0.68 ms per proof at 2^14 / 2^15 /
+        // 2^16 for eight instead of four, profiles/r04af_batch_sweep.txt).
         uint32_t batch = 0;
         if (queueMode()) {
             const char *be = getenv("ZKHIP_BATCH");
-            batch = be ? (uint32_t)strtoul(be, nullptr, 10) : (hdr->domainSize <= (1u << 17) ? 4u : 0u);
+            batch = be ? (uint32_t)strtoul(be, nullptr, 10) : (hdr->domainSize <= (1u << 16) ? 8u : hdr->domainSize <= (1u << 17) ? 4u : 0u);
         }
         // every slot and lane the pipeline will walk is allocated at start-up (an out-of-memory there falls back to the tables
         // as in the zkey, or ends the start — never a proof later)
