@@ -1,5 +1,5 @@
 #!/bin/bash
-# second look at the hardware queues: unset (the runtime's default) against 8 / 16 / 24 / 32, two alternations
+# second look at the hardware queues: unset (= 16: the library sets it when the process has not) against 8 / 16 / 24 / 32, two alternations
 export TMPDIR=/tmp
 o=gpurun_out/r04ah; mkdir -p $o
 ( for rep in 1 2; do for k in 14 16 18 20; do for hq in unset 8 16 24 32; do
