@@ -40,17 +40,26 @@ struct HostTail {
                                const uint8_t pi_b[128], const uint8_t pi_c[64],
                                const uint8_t r32[32], const uint8_t s32[32],
                                uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
+    // The part of the tail that needs (r, s) and the key but NOT the MSM sums — r*delta1, s*delta1, rs*delta1, s*delta2, about
+    // 0.13 of the tail's 0.3 ms — so that a collecting thread can do it BEFORE it waits for the GPU.  Opaque (the point types are
+    // host_tail.cpp's).  prepare_rs draws r32 / s32 when they are NULL; nonzero = the random source failed.
+    struct RsPart {
+        alignas(16) uint8_t blob[800];
+    };
+    static int prepare_rs(const uint8_t vk_delta1[64], const uint8_t vk_delta2[128], const uint8_t *r32, const uint8_t *s32, RsPart *out);
     // the same from the GPU's window sums (XYZZ; G1: A, B1, C [Ww each] then H [Wh]; G2: B2 [Ww]); r32 / s32 NULL = drawn
     // like the reference's randombytes_buf(31 bytes).  Returns nonzero when the random source fails.
     static int finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
                                    const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
                                    const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
-                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
+                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64],
+                                   const RsPart *pre = nullptr);        // pre given: (r32, s32) are ignored — they are in it
     static int finish_from_records(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
                                    const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
                                    const uint8_t *wa, const uint8_t *wb1, const uint8_t *wc, const uint8_t *wh, const uint8_t *wb2,
                                    uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
-                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]);
+                                   const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64],
+                                   const RsPart *pre = nullptr);
     // canonical base-10 of a 32-byte LE integer
     static std::string to_dec(const uint8_t le32[32]);
     // de-Montgomery an Fq element and print base-10 (E.f1.toString, src/groth16.cpp:274)

@@ -10,6 +10,7 @@
 #include <sys/random.h>
 #include <list>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -229,15 +230,18 @@ static void three_to_affine(const G1P &a, const G2P &b, const G1P &c, G1A &A, G2
     B = G2A{Fq2h::mul(b.x, Fq2h::mul(ib, b.zzz)), Fq2h::mul(b.y, Fq2h::mul(ib, b.zz))};
 }
 
-static void assemble_core(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
-                          const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
-                          const G1P &pih, G1P pi_a, G1P pib1, G2P pi_b, G1P pi_c,
-                          const uint8_t r32[32], const uint8_t s32[32],
-                          uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
-    u32 r[8], s[8], rs[8];
-    memcpy(r, r32, 32);
-    memcpy(s, s32, 32);
+// what the tail needs of (r, s) and the key alone (HostTail::RsPart is this, opaque)
+struct RsPoints {
+    u32 r[8], s[8];
+    G1P r_delta1, s_delta1, rs_delta1;
+    G2P s_delta2;
+};
+static_assert(sizeof(RsPoints) <= sizeof(HostTail::RsPart) && alignof(RsPoints) <= 16, "RsPart too small");
 
+static void rs_points(const uint8_t vk_delta1[64], const uint8_t vk_delta2[128], const uint8_t r32[32], const uint8_t s32[32], RsPoints &o) {
+    u32 rs[8];
+    memcpy(o.r, r32, 32);
+    memcpy(o.s, s32, 32);
     // rs = toMontgomery(mul(r, s)) = r*s mod r_BN in standard form (:242-243)
     Fr64 fr, fs;
     memcpy(fr.v, r32, 32);
@@ -246,19 +250,25 @@ static void assemble_core(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64
     memcpy(rs, frs.v, 32);
 
     const std::shared_ptr<const DeltaTables> tb = delta_tables(vk_delta1, vk_delta2);
-    G1P r_delta1, s_delta1, rs_delta1;
-    G2P s_delta2;
     if (!tb->d1.t.empty()) {
-        r_delta1 = tb->d1.mul(r);
-        s_delta1 = tb->d1.mul(s);
-        rs_delta1 = tb->d1.mul(rs);
+        o.r_delta1 = tb->d1.mul(o.r);
+        o.s_delta1 = tb->d1.mul(o.s);
+        o.rs_delta1 = tb->d1.mul(rs);
     } else {
         const G1P delta1 = G1P::from_affine(load<G1A>(vk_delta1));
-        r_delta1 = scalar_mul(delta1, r);
-        s_delta1 = scalar_mul(delta1, s);
-        rs_delta1 = scalar_mul(delta1, rs);
+        o.r_delta1 = scalar_mul(delta1, o.r);
+        o.s_delta1 = scalar_mul(delta1, o.s);
+        o.rs_delta1 = scalar_mul(delta1, rs);
     }
-    s_delta2 = !tb->d2.t.empty() ? tb->d2.mul(s) : scalar_mul(G2P::from_affine(load<G2A>(vk_delta2)), s);
+    o.s_delta2 = !tb->d2.t.empty() ? tb->d2.mul(o.s) : scalar_mul(G2P::from_affine(load<G2A>(vk_delta2)), o.s);
+}
+
+static void assemble_core(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
+                          const G1P &pih, G1P pi_a, G1P pib1, G2P pi_b, G1P pi_c, const RsPoints &rsp,
+                          uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
+    const u32 *r = rsp.r, *s = rsp.s;
+    const G1P &r_delta1 = rsp.r_delta1, &s_delta1 = rsp.s_delta1, &rs_delta1 = rsp.rs_delta1;
+    const G2P &s_delta2 = rsp.s_delta2;
 
     madd(pi_a, load<G1A>(vk_alpha1));                       // groth16.cpp:222
     add(pi_a, r_delta1);                                    // :223-224
@@ -283,9 +293,11 @@ void HostTail::final_assembly(const uint8_t vk_alpha1[64], const uint8_t vk_beta
                               const uint8_t pi_b_b[128], const uint8_t pi_c_b[64],
                               const uint8_t r32[32], const uint8_t s32[32],
                               uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
-    assemble_core(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, G1P::from_affine(load<G1A>(pih_b)),
+    RsPoints rsp;
+    rs_points(vk_delta1, vk_delta2, r32, s32, rsp);
+    assemble_core(vk_alpha1, vk_beta1, vk_beta2, G1P::from_affine(load<G1A>(pih_b)),
                   G1P::from_affine(load<G1A>(pi_a_b)), G1P::from_affine(load<G1A>(pib1_b)), G2P::from_affine(load<G2A>(pi_b_b)),
-                  G1P::from_affine(load<G1A>(pi_c_b)), r32, s32, outA, outB, outC);
+                  G1P::from_affine(load<G1A>(pi_c_b)), rsp, outA, outB, outC);
 }
 
 static int draw31(uint8_t out[32]) {
@@ -305,10 +317,19 @@ static int draw31(uint8_t out[32]) {
 int HostTail::finish_from_windows(const uint8_t vk_alpha1[64], const uint8_t vk_beta1[64], const uint8_t vk_beta2[128],
                                   const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
                                   const uint8_t *w1, const uint8_t *w2, uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
-                                  const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
+                                  const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64],
+                                  const RsPart *pre) {
     const size_t M1 = (size_t)Ww * rcw * sizeof(G1P);      // one MSM's records
     return finish_from_records(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, w1, w1 + M1, w1 + 2 * M1, w1 + 3 * M1, w2,
-                               Ww, cw, rcw, Wh, ch, rch, r32, s32, outA, outB, outC);
+                               Ww, cw, rcw, Wh, ch, rch, r32, s32, outA, outB, outC, pre);
+}
+
+int HostTail::prepare_rs(const uint8_t vk_delta1[64], const uint8_t vk_delta2[128], const uint8_t *r32, const uint8_t *s32, RsPart *out) {
+    uint8_t r[32], s[32];
+    if (r32) memcpy(r, r32, 32); else if (draw31(r)) return 1;
+    if (s32) memcpy(s, s32, 32); else if (draw31(s)) return 1;
+    rs_points(vk_delta1, vk_delta2, r, s, *new (out->blob) RsPoints);
+    return 0;
 }
 
 // the same with the five MSMs' records given one by one (a batched submission keeps one bucket set per proof)
@@ -316,10 +337,17 @@ int HostTail::finish_from_records(const uint8_t vk_alpha1[64], const uint8_t vk_
                                   const uint8_t vk_delta1[64], const uint8_t vk_delta2[128],
                                   const uint8_t *wa, const uint8_t *wb1, const uint8_t *wc, const uint8_t *wh, const uint8_t *wb2,
                                   uint32_t Ww, uint32_t cw, uint32_t rcw, uint32_t Wh, uint32_t ch, uint32_t rch,
-                                  const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64]) {
-    uint8_t r[32], s[32];
-    if (r32) memcpy(r, r32, 32); else if (draw31(r)) return 1;
-    if (s32) memcpy(s, s32, 32); else if (draw31(s)) return 1;
+                                  const uint8_t *r32, const uint8_t *s32, uint8_t outA[64], uint8_t outB[128], uint8_t outC[64],
+                                  const RsPart *pre) {
+    RsPoints mine;
+    const RsPoints *rsp = pre ? reinterpret_cast<const RsPoints *>(pre->blob) : nullptr;
+    if (!rsp) {
+        uint8_t r[32], s[32];
+        if (r32) memcpy(r, r32, 32); else if (draw31(r)) return 1;
+        if (s32) memcpy(s, s32, 32); else if (draw31(s)) return 1;
+        rs_points(vk_delta1, vk_delta2, r, s, mine);
+        rsp = &mine;
+    }
     G1P a, b1, c, h;
     G2P b2;
     if (Ww > 1 || Wh > 1) {            // plain tables: five Horner chains of W*c doublings, one host thread each
@@ -339,7 +367,7 @@ int HostTail::finish_from_records(const uint8_t vk_alpha1[64], const uint8_t vk_
         h = horner<G1P>(wh, Wh, ch, rch);
         b2 = horner<G2P>(wb2, Ww, cw, rcw);
     }
-    assemble_core(vk_alpha1, vk_beta1, vk_beta2, vk_delta1, vk_delta2, h, a, b1, b2, c, r, s, outA, outB, outC);
+    assemble_core(vk_alpha1, vk_beta1, vk_beta2, h, a, b1, b2, c, *rsp, outA, outB, outC);
     return 0;
 }
 

@@ -1052,8 +1052,20 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
     const uint32_t tbw = c.tbw, Ww = c.Ww;
     const uint64_t ew = c.ew;
     const MsmPlan pw = c.pw;
-    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, c.tail_of(4));
+    // A LONE proof (nothing else in flight: slot 0, lane 0) has an idle stream — the finishing one, which only joins and copies
+    // at the very end.  The merges and the bucket reduction of MSM B2 go there instead of standing in stream 2's line: the
+    // A|B1|C launch starts right behind the G2 level-1 launch, and the G2 reduction no longer ends the proof.  Medians of 16
+    // synchronous proofs, three alternations (profiles/r04an_g2_aside_medians.txt): 2^14 1.61 -> 1.37 ms, 2^16 2.31 -> 1.88,
+    // 2^17 2.98 -> 2.58, 2^18 4.46 -> 4.18, 2^19 7.52 -> 7.35; at 2^22 it LOSES 0.2-2 ms (r04am: the merges then run beside the
+    // chip-filling A|B1|C launch, which they slow down more than their own 0.5 ms), hence the size limit.
+    static const uint32_t g2_aside_maxlog = [] { const char *e = probe_env("ZKHIP_G2_ASIDE_MAXLOG"); return e ? (uint32_t)atoi(e) : 19u; }();
+    const bool g2_aside = !tails && p->batch_abc && c.sf != s2 && c.sf != c.s && p->in_flight == 0 && !p->capturing && !p->use_graph &&
+                          p->logn <= g2_aside_maxlog;
+    AccumTail t4 = c.tail_of(4);
+    if (g2_aside) t4.stream = c.sf;
+    launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, t4);
     if (tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, c.tail[4]);
+    else if (g2_aside) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, c.sf);
     if (p->batch_abc) {
         // small circuits: MSM A, B1 and C (same scalars, same sorted entries) in ONE set of launches —
         // level-1 accumulation, merges and bucket reduction each cost what one MSM's cost
@@ -1067,7 +1079,7 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
         launch_msm_accum_g1_batch(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, b, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
         if (tm) for (int e : {13, 14, 15, 16}) HIP_TRY(hipEventRecord(q.ev[e], s2));      // (B1 and C have no launch of their own)
         launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 3, pw, c.after(0, s2));
-        if (!tails) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
+        if (!tails && !g2_aside) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
         HIP_TRY(hipEventRecord(q.ev_join, s2));
     } else {
     launch_msm_accum_g1(c.bA, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsA.p, 0, 0, tbw, ew, q.acc_ws_g1[0], q.acc_key[0], q.acc_flag[0], s2, tm ? &q.ev[8] : nullptr, c.tail_of(0));
@@ -1399,6 +1411,23 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
     }
     zk_prover::ProofSlot &q = *qp;
     DeviceGuard g(p->device);
+    // What the tail needs of (r, s) alone — four fixed-base multiplications of delta, 0.13 of the tail's 0.3 ms — is done HERE,
+    // before the wait: a synchronous zk_prove spends it while the GPU works instead of behind it (2^14: 1.37 ms of which 0.3 tail).
+    HostTail::RsPart rs_pre[ZK_MAX_BATCH];
+    int rs_failed = 0;
+    if (direct) {
+        std::atomic<int> failed{0};
+        tail_pool().for_each(p->batch > 1 ? q.count : 1u, [&](uint32_t k) {
+            const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[k] : nullptr) : direct->r32;
+            const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[k] : nullptr) : direct->s32;
+            try {
+                if (HostTail::prepare_rs(p->vk_delta1, p->vk_delta2, r32, s32, &rs_pre[k])) failed.store(1);
+            } catch (...) {
+                failed.store(2);
+            }
+        });
+        rs_failed = failed.load();
+    }
     const hipError_t done = hipEventSynchronize(q.via_graph ? q.ev_gdone : q.ev_done);
     // the slot is retired whatever happens below (a failed proof must not wedge the queue), but only
     // AFTER the wait and the host tail: nobody may reuse its buffers while they are still read
@@ -1413,6 +1442,7 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
         }
     } retire{p, q};
     HIP_TRY(done);
+    if (rs_failed) throw std::runtime_error(rs_failed == 1 ? "getrandom failed" : "host tail of a proof failed");
     if (rs) {
         rs->have_r = q.have_r;
         rs->have_s = q.have_s;
@@ -1455,12 +1485,11 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
         const size_t Rw = (size_t)rcw * sizeof(G1XYZZ), Rh = (size_t)rch * sizeof(G1XYZZ), R2 = (size_t)rcw * sizeof(G2XYZZ);
         std::atomic<int> failed{0};
         tail_pool().for_each(q.count, [&](uint32_t k) {
-            const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[k] : nullptr) : direct->r32;
-            const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[k] : nullptr) : direct->s32;
             try {
                 if (HostTail::finish_from_records(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2,
                                                   w1 + k * Rw, w1 + M1 + k * Rw, w1 + 2 * M1 + k * Rw, w1 + 3 * M1 + k * Rh, w2 + k * R2,
-                                                  1, cw, rcw, 1, ch, rch, r32, s32, direct->out[k].A, direct->out[k].B, direct->out[k].C))
+                                                  1, cw, rcw, 1, ch, rch, nullptr, nullptr, direct->out[k].A, direct->out[k].B, direct->out[k].C,
+                                                  &rs_pre[k]))
                     failed.store(1);
             } catch (...) {
                 failed.store(2);
@@ -1470,10 +1499,8 @@ static void collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs = nullp
         return;
     }
     if (direct) {
-        const uint8_t *r32 = direct->use_submitted ? (q.have_r ? q.r32[0] : nullptr) : direct->r32;
-        const uint8_t *s32 = direct->use_submitted ? (q.have_s ? q.s32[0] : nullptr) : direct->s32;
         if (HostTail::finish_from_windows(p->vk_alpha1, p->vk_beta1, p->vk_beta2, p->vk_delta1, p->vk_delta2, w1, w2, Ww, cw, rcw, Wh, ch, rch,
-                                          r32, s32, direct->out->A, direct->out->B, direct->out->C))
+                                          nullptr, nullptr, direct->out->A, direct->out->B, direct->out->C, &rs_pre[0]))
             throw std::runtime_error("getrandom failed");
         return;
     }
