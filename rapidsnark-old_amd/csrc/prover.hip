@@ -1061,6 +1061,8 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
     static const uint32_t g2_aside_maxlog = [] { const char *e = probe_env("ZKHIP_G2_ASIDE_MAXLOG"); return e ? (uint32_t)atoi(e) : 19u; }();
     const bool g2_aside = !tails && p->batch_abc && c.sf != s2 && c.sf != c.s && p->in_flight == 0 && !p->capturing && !p->use_graph &&
                           p->logn <= g2_aside_maxlog;
+    // (The WHOLE MSM B2 there, its level-1 launch beside the A|B1|C one, was measured too: nothing at 2^14 ... 2^16, +4-7 % at
+    // 2^17 / 2^18, profiles/r04ap_g2_whole_aside.txt.)
     AccumTail t4 = c.tail_of(4);
     if (g2_aside) t4.stream = c.sf;
     launch_msm_accum_g2(q.buckets_g2.p, q.sort_w.offsets.p, q.sort_w.entries.p, p->ptsB2.p, 0, 0, tbw, ew, q.acc_ws_g2.p, q.acc_key[4], q.acc_flag[4], s2, tm ? &q.ev[10] : nullptr, t4);
