@@ -1059,7 +1059,7 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
     // 2^17 2.98 -> 2.58, 2^18 4.46 -> 4.18, 2^19 7.52 -> 7.35; at 2^22 it LOSES 0.2-2 ms (r04am: the merges then run beside the
     // chip-filling A|B1|C launch, which they slow down more than their own 0.5 ms), hence the size limit.
     static const uint32_t g2_aside_maxlog = [] { const char *e = probe_env("ZKHIP_G2_ASIDE_MAXLOG"); return e ? (uint32_t)atoi(e) : 19u; }();
-    const bool g2_aside = !tails && p->batch_abc && c.sf != s2 && c.sf != c.s && p->in_flight == 0 && !p->capturing && !p->use_graph &&
+    const bool g2_aside = !tails && c.sf != s2 && c.sf != c.s && p->in_flight == 0 && !p->capturing && !p->use_graph &&
                           p->logn <= g2_aside_maxlog;
     // (The WHOLE MSM B2 there, its level-1 launch beside the A|B1|C one, was measured too: nothing at 2^14 ... 2^16, +4-7 % at
     // 2^17 / 2^18, profiles/r04ap_g2_whole_aside.txt.)
@@ -1091,7 +1091,7 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
         launch_msm_reduce_g1(q.wsum_g1.p + Ww, q.scratch_g1.p + msm_reduce_scratch_points(1, pw), c.bB1, 1, pw, c.tail[1]);
     } else {
         // bucket reductions stay on the stream of their MSMs
-        launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
+        if (!g2_aside) launch_msm_reduce_g2(q.wsum_g2.p, q.scratch_g2.p, q.buckets_g2.p, 1, pw, s2);
         launch_msm_reduce_g1(q.wsum_g1.p, q.scratch_g1.p, c.bA, 2, pw, s2);
     }
     HIP_TRY(hipEventRecord(q.ev_join, s2));
