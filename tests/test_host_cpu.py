@@ -206,3 +206,20 @@ def test_assemble_random_scalars_against_the_group_law(zk):
         C = G1.sub(C, G1.mul(delta1, r * s % bn.R_MOD))
         want = bn.g1_to_bytes(A) + bn.g2_to_bytes(B) + bn.g1_to_bytes(C)
         assert zk.assemble(vk, [sums], r, s) == want, (i, r, s)
+
+
+def test_tail_pool_runs_every_item_once_under_concurrent_callers(tmp_path):
+    """csrc/tail_pool.hpp (the host tails of a batched submission run on it, several provers share it): six caller threads,
+    thousands of for_each calls with 1..8 items — every item exactly once, no call returns early; a second build under
+    ThreadSanitizer must stay silent (skipped where the sanitizer runtime is not installed)."""
+    import subprocess
+    src = os.path.join(ROOT, "tools", "tail_pool_test.cpp")
+    inc = os.path.join(ROOT, "rapidsnark-old_amd", "csrc")
+    exe = str(tmp_path / "tail_pool_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", inc, src, "-o", exe])
+    out = subprocess.run([exe, "6", "3000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and " 0 wrong counts" in out.stdout, out.stdout + out.stderr
+    tsan = str(tmp_path / "tail_pool_test_tsan")
+    if subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", inc, src, "-o", tsan], capture_output=True).returncode == 0:
+        out = subprocess.run([tsan, "6", "800"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "ThreadSanitizer" not in out.stderr and " 0 wrong counts" in out.stdout, out.stdout + out.stderr[-2000:]
