@@ -996,7 +996,7 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
     // chip-filling A|B1|C launch, which they slow down more than their own 0.5 ms), hence the size limit.
     static const uint32_t g2_aside_maxlog = [] { const char *e = probe_env("ZKHIP_G2_ASIDE_MAXLOG"); return e ? (uint32_t)atoi(e) : 19u; }();
     const bool g2_aside = !tails && c.sf != s2 && c.sf != c.s && p->in_flight == 0 && !p->capturing && !p->use_graph &&
-                          p->logn <= g2_aside_maxlog;
+                          p->sv.size() <= ((uint64_t)1 << g2_aside_maxlog);      // (the witness slice: a shard of a large proof is a small MSM)
     // (The WHOLE MSM B2 there, its level-1 launch beside the A|B1|C one, was measured too: nothing at 2^14 ... 2^16, +4-7 % at
     // 2^17 / 2^18, profiles/r04ap_g2_whole_aside.txt.)
     AccumTail t4 = c.tail_of(4);
