@@ -58,6 +58,57 @@ DEFINE_KERNEL32(k_mov_b32, "v_mov_b32 %0, %1")
 DEFINE_KERNEL32(k_fma_f32, "v_fma_f32 %0, %1, %2, %0")
 DEFINE_KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0", "vcc")
 DEFINE_KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %0", "memory")
+DEFINE_KERNEL64(k_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %2, %0", "vcc")
+DEFINE_KERNEL64(k_ashrrev_i64, "v_ashrrev_i64 %0, 29, %0", "memory")
+DEFINE_KERNEL64(k_lshlrev_b64, "v_lshlrev_b64 %0, 3, %0", "memory")
+DEFINE_KERNEL64(k_mov_b64, "v_mov_b64 %0, %0", "memory")
+DEFINE_KERNEL32(k_alignbit_b32, "v_alignbit_b32 %0, %1, %0, 29")
+DEFINE_KERNEL32(k_ashrrev_i32, "v_ashrrev_i32 %0, 29, %0")
+DEFINE_KERNEL32(k_and_b32, "v_and_b32 %0, %1, %0")
+DEFINE_KERNEL32(k_and_lit, "v_and_b32 %0, 0x1fffffff, %0")
+DEFINE_KERNEL32(k_sub_u32, "v_sub_u32 %0, %1, %0")
+DEFINE_KERNEL32(k_bfe_i32, "v_bfe_i32 %0, %0, 0, 29")
+DEFINE_KERNEL32(k_lshl_add_u32, "v_lshl_add_u32 %0, %0, 3, %1")
+DEFINE_KERNEL32(k_and_or_b32, "v_and_or_b32 %0, %0, %1, %2")
+DEFINE_KERNEL32(k_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+DEFINE_KERNEL32(k_cndmask, "v_cndmask_b32 %0, %1, %0, vcc")
+DEFINE_KERNEL32(k_mov_dpp, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+// (the plain `v_cndmask_b32 ..., vcc` lines of this probe read 16-23 cycles per instruction; that is this probe's own loop — a proof-level
+// A/B of the G2 level-1 kernel with its 63 in-loop v_cndmask_b32_e32 replaced by xor / sub / and on an opaque lane mask moved its
+// launch 11.33 -> 11.29 ms, profiles/r04aw_ab_fq2_without_cndmask.txt: in compiled code the instruction costs what the others do)
+// v_cndmask with a lane mask that is really there: e64 form on an SGPR pair, and the e32 form on vcc written once in front of the loop
+__global__ void k_cndmask_e64(uint32_t *out, uint32_t seed) {
+    uint32_t a = seed + threadIdx.x, b = seed * 3 + 1;
+    uint64_t m = __ballot((threadIdx.x & 1u) != 0);
+    uint32_t r0 = a, r1 = a + 1, r2 = a + 2, r3 = a + 3, r4 = a + 4, r5 = a + 5, r6 = a + 6, r7 = a + 7;
+    for (int i = 0; i < ITERS; i++) {
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r0) : "v"(a), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r1) : "v"(b), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r2) : "v"(a), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r3) : "v"(b), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r4) : "v"(a), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r5) : "v"(b), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r6) : "v"(a), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r7) : "v"(b), "s"(m));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+}
+__global__ void k_cndmask_vcc(uint32_t *out, uint32_t seed) {
+    uint32_t a = seed + threadIdx.x, b = seed * 3 + 1;
+    uint32_t r0 = a, r1 = a + 1, r2 = a + 2, r3 = a + 3, r4 = a + 4, r5 = a + 5, r6 = a + 6, r7 = a + 7;
+    for (int i = 0; i < ITERS; i++) {
+        asm volatile("v_cmp_lt_u32 vcc, %8, %9\n s_nop 4\n"
+                     "v_cndmask_b32 %0, %8, %0, vcc\n v_cndmask_b32 %1, %9, %1, vcc\n v_cndmask_b32 %2, %8, %2, vcc\n v_cndmask_b32 %3, %9, %3, vcc\n"
+                     "v_cndmask_b32 %4, %8, %4, vcc\n v_cndmask_b32 %5, %9, %5, vcc\n v_cndmask_b32 %6, %8, %6, vcc\n v_cndmask_b32 %7, %9, %7, vcc\n"
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+}
+DEFINE_KERNEL32(k_bfi_b32, "v_bfi_b32 %0, %1, %2, %0")
+DEFINE_KERNEL32(k_xor_b32, "v_xor_b32 %0, %1, %0")
+DEFINE_KERNEL32(k_or_b32, "v_or_b32 %0, %1, %0")
+DEFINE_KERNEL32(k_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+DEFINE_KERNEL32(k_add_co, "v_add_co_u32 %0, vcc, %1, %0")
 DEFINE_KERNEL64(k_fma_f64, "v_fma_f64 %0, %0, %0, %0", "memory")
 DEFINE_KERNEL64(k_mul_f64, "v_mul_f64 %0, %0, %0", "memory")
 
@@ -148,6 +199,28 @@ int main() {
     RUN("v_mul_hi_u32_u24", k_mul_hi_u32_u24, 8)
     RUN("v_mad_u64_u32", k_mad_u64_u32, 8)
     RUN("v_lshl_add_u64", k_lshl_add_u64, 8)
+    RUN("v_mad_i64_i32", k_mad_i64_i32, 8)
+    RUN("v_ashrrev_i64", k_ashrrev_i64, 8)
+    RUN("v_lshlrev_b64", k_lshlrev_b64, 8)
+    RUN("v_mov_b64", k_mov_b64, 8)
+    RUN("v_alignbit_b32", k_alignbit_b32, 8)
+    RUN("v_ashrrev_i32", k_ashrrev_i32, 8)
+    RUN("v_and_b32", k_and_b32, 8)
+    RUN("v_and_b32 literal", k_and_lit, 8)
+    RUN("v_sub_u32", k_sub_u32, 8)
+    RUN("v_bfe_i32", k_bfe_i32, 8)
+    RUN("v_lshl_add_u32", k_lshl_add_u32, 8)
+    RUN("v_and_or_b32", k_and_or_b32, 8)
+    RUN("v_lshlrev_b32", k_lshlrev_b32, 8)
+    RUN("v_cndmask_b32", k_cndmask, 8)
+    RUN("v_mov_b32 dpp", k_mov_dpp, 8)
+    RUN("v_cndmask e64 sgpr", k_cndmask_e64, 8)
+    RUN("v_cndmask e32 vcc", k_cndmask_vcc, 8)
+    RUN("v_bfi_b32", k_bfi_b32, 8)
+    RUN("v_xor_b32", k_xor_b32, 8)
+    RUN("v_or_b32", k_or_b32, 8)
+    RUN("v_lshrrev_b32", k_lshrrev_b32, 8)
+    RUN("v_add_co_u32", k_add_co, 8)
     RUN("v_fma_f64", k_fma_f64, 8)
     RUN("v_mul_f64", k_mul_f64, 8)
     RUN("addc chain(8)", k_addc_chain, 8)
