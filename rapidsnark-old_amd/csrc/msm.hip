@@ -94,6 +94,21 @@ __device__ __forceinline__ F load_el(const F *p) {
     r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
     return r;
 }
+// a table row is read exactly once per MSM: ZK_L1_NT_GATHER (measurement builds) loads it with the non-temporal hint
+template <class F>
+__device__ __forceinline__ F load_row_el(const F *p) {
+#if defined(ZK_L1_NT_GATHER)
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u *q = reinterpret_cast<const v4u *>(p);
+    v4u lo = __builtin_nontemporal_load(q), hi = __builtin_nontemporal_load(q + 1);
+    F r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+#else
+    return load_el(p);
+#endif
+}
 template <class F>
 __device__ __forceinline__ void store_el(F *p, const F &r) {
     uint4 *q = reinterpret_cast<uint4 *>(p);
@@ -636,8 +651,8 @@ __global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G1_L1_WAVES void k_msm_accum_l1(G1A
             nextSkip = idx < idx_min;
             bend2 = offsets[b + 2 < nbuckets_total ? b + 2 : nbuckets_total];
             const Affine<F> *src = points + (nextSkip ? 0 : ZK_GATHER_ROW(idx - idx_sub));
-            nextP.x = load_el(&src->x);
-            nextP.y = load_el(&src->y);
+            nextP.x = load_row_el(&src->x);
+            nextP.y = load_row_el(&src->y);
             entNext = entries[pos + 1 < hi ? pos + 1 : hi - 1];
         };
         uint32_t e = lo;
@@ -741,8 +756,8 @@ __global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s
             nextSkip = idx < idx_min;
             bend2 = offsets[b + 2 < nbuckets_total ? b + 2 : nbuckets_total];
             const Fq *src = reinterpret_cast<const Fq *>(points + (nextSkip ? 0 : idx - idx_sub)) + comp;
-            nextX = load_el(src);
-            nextY = load_el(src + 2);
+            nextX = load_row_el(src);
+            nextY = load_row_el(src + 2);
             entNext = entries[pos + 1 < hi ? pos + 1 : hi - 1];
         };
         uint32_t e = lo;
