@@ -30,19 +30,19 @@
         out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7; \
     }
 
-#define DEFINE_KERNEL64(name, ASM, CLOB)                                                \
+#define DEFINE_KERNEL64(name, ASM, ...)                                                \
     __global__ void name(uint32_t *out, uint32_t seed) {                                    \
         uint32_t a = seed + threadIdx.x, b = seed * 3 + 1;                                  \
         uint64_t r0 = a, r1 = a + 1, r2 = a + 2, r3 = a + 3, r4 = a + 4, r5 = a + 5, r6 = a + 6, r7 = a + 7; \
         for (int i = 0; i < ITERS; i++) {                                                   \
-            asm volatile(ASM : "+v"(r0) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r1) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r2) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r3) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r4) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r5) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r6) : "v"(a), "v"(b) : CLOB);                           \
-            asm volatile(ASM : "+v"(r7) : "v"(a), "v"(b) : CLOB);                           \
+            asm volatile(ASM : "+v"(r0) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r1) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r2) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r3) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r4) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r5) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r6) : "v"(a), "v"(b) : __VA_ARGS__);                           \
+            asm volatile(ASM : "+v"(r7) : "v"(a), "v"(b) : __VA_ARGS__);                           \
         }                                                                                   \
         uint64_t x = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;                                 \
         out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)x ^ (uint32_t)(x >> 32);    \
@@ -109,6 +109,22 @@ DEFINE_KERNEL32(k_xor_b32, "v_xor_b32 %0, %1, %0")
 DEFINE_KERNEL32(k_or_b32, "v_or_b32 %0, %1, %0")
 DEFINE_KERNEL32(k_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
 DEFINE_KERNEL32(k_add_co, "v_add_co_u32 %0, vcc, %1, %0")
+DEFINE_KERNEL64(k_mad_i64_sgpr, "v_mad_i64_i32 %0, s[20:21], %1, %2, %0", "s20", "s21")
+DEFINE_KERNEL64(k_mad_i64_zero, "v_mad_i64_i32 %0, vcc, %1, %2, 0", "vcc")
+// two accumulators fed alternately by each statement: the chain of one never issues back to back
+__global__ void k_mad_i64_pairs(uint32_t *out, uint32_t seed) {
+    uint32_t a = seed + threadIdx.x, b = seed * 3 + 1;
+    uint64_t r0 = a, r1 = a + 1, r2 = a + 2, r3 = a + 3, r4 = a + 4, r5 = a + 5, r6 = a + 6, r7 = a + 7;
+    for (int i = 0; i < ITERS / 2; i++) {
+        asm volatile("v_mad_i64_i32 %0, s[20:21], %8, %9, %0\n v_mad_i64_i32 %1, s[22:23], %8, %9, %1\n v_mad_i64_i32 %2, s[20:21], %8, %9, %2\n v_mad_i64_i32 %3, s[22:23], %8, %9, %3\n"
+                     "v_mad_i64_i32 %4, s[20:21], %8, %9, %4\n v_mad_i64_i32 %5, s[22:23], %8, %9, %5\n v_mad_i64_i32 %6, s[20:21], %8, %9, %6\n v_mad_i64_i32 %7, s[22:23], %8, %9, %7\n"
+                     "v_mad_i64_i32 %0, s[20:21], %8, %9, %0\n v_mad_i64_i32 %1, s[22:23], %8, %9, %1\n v_mad_i64_i32 %2, s[20:21], %8, %9, %2\n v_mad_i64_i32 %3, s[22:23], %8, %9, %3\n"
+                     "v_mad_i64_i32 %4, s[20:21], %8, %9, %4\n v_mad_i64_i32 %5, s[22:23], %8, %9, %5\n v_mad_i64_i32 %6, s[20:21], %8, %9, %6\n v_mad_i64_i32 %7, s[22:23], %8, %9, %7\n"
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b) : "s20", "s21", "s22", "s23");
+    }
+    uint64_t x = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)x ^ (uint32_t)(x >> 32);
+}
 DEFINE_KERNEL64(k_fma_f64, "v_fma_f64 %0, %0, %0, %0", "memory")
 DEFINE_KERNEL64(k_mul_f64, "v_mul_f64 %0, %0, %0", "memory")
 
@@ -200,6 +216,9 @@ int main() {
     RUN("v_mad_u64_u32", k_mad_u64_u32, 8)
     RUN("v_lshl_add_u64", k_lshl_add_u64, 8)
     RUN("v_mad_i64_i32", k_mad_i64_i32, 8)
+    RUN("v_mad_i64_i32 -> sgpr pair", k_mad_i64_sgpr, 8)
+    RUN("v_mad_i64_i32 addend 0", k_mad_i64_zero, 8)
+    RUN("v_mad_i64_i32 block of 16", k_mad_i64_pairs, 8)
     RUN("v_ashrrev_i64", k_ashrrev_i64, 8)
     RUN("v_lshlrev_b64", k_lshlrev_b64, 8)
     RUN("v_mov_b64", k_mov_b64, 8)
