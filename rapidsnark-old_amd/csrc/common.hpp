@@ -67,3 +67,30 @@ struct HostTail {
 };
 
 }   // namespace zk
+
+// Wave priority (s_setprio) by what a kernel is — the level-1 bucket accumulations, which fill the chip for milliseconds, stay at 0:
+//   3  the follow-up kernels (merges of the cut runs, bucket reductions): chains of dependent additions in a handful of waves;
+//      beside a level-1 launch each of their waves shares its SIMD's issue port with three level-1 waves
+//   1  the kernels of the two sort chains and of the transform chain (SpMV, passes, abc -> h): what the NEXT level-1 launch of
+//      their proof waits for
+// Queue / stream priorities only order the DISPATCH of workgroups (measured earlier: nothing for unsharded provers); this is the
+// SIMD's issue arbiter.  Same box, three alternations (profiles/r04bg_*, r04bh_*): pipelined period 2^14 0.612 -> 0.567 ms,
+// 2^16 1.005 -> 0.938, 2^18 2.81 -> 2.62, 2^20 9.18 -> 8.95, 2^22 32.46 -> 32.30 (witness resident; with host witnesses the same
+// ratios); synchronous proofs and shards equal.  Follow-ups alone: -5 ... -7 % up to 2^18, nothing above; chains at 2 instead
+// of 1: equal.  -DZK_TAIL_WAVE_PRIO=0 -DZK_CHAIN_WAVE_PRIO=0 builds the library without.
+#ifndef ZK_TAIL_WAVE_PRIO
+#define ZK_TAIL_WAVE_PRIO 3
+#endif
+#if ZK_TAIL_WAVE_PRIO
+#define ZK_TAIL_PRIO() __builtin_amdgcn_s_setprio(ZK_TAIL_WAVE_PRIO)
+#else
+#define ZK_TAIL_PRIO() ((void)0)
+#endif
+#ifndef ZK_CHAIN_WAVE_PRIO
+#define ZK_CHAIN_WAVE_PRIO 1
+#endif
+#if ZK_CHAIN_WAVE_PRIO
+#define ZK_CHAIN_PRIO() __builtin_amdgcn_s_setprio(ZK_CHAIN_WAVE_PRIO)
+#else
+#define ZK_CHAIN_PRIO() ((void)0)
+#endif

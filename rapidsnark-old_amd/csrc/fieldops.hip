@@ -1,4 +1,5 @@
 // Pointwise Fr/Fq kernels and the sparse A.w / B.w accumulation (src/groth16.cpp:56-96).
+#include "common.hpp"
 #include "kernels.hpp"
 #include "hipcheck.hpp"
 #include "field29.hpp"
@@ -51,6 +52,7 @@ void launch_fq_mul_vec(Fq *out, const Fq *a, const Fq *b, uint64_t n, hipStream_
 // the standard-form witness gives w*value in this library's 2^261 form (field29.hpp).
 // blockIdx.y = vector of a batched submission: its witness at wtns + y * wtns_stride, its a|b|c at + y * abc_stride
 __global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, uint64_t abc_stride, uint64_t wtns_stride) {
+    ZK_CHAIN_PRIO();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     a += (uint64_t)blockIdx.y * abc_stride;

@@ -279,6 +279,7 @@ template <> struct LaneModel<Fq2> {
 // key = (|d| - 1) + w * nbuckets with per-window bucket sets, |d| - 1 with window-precomputed
 // tables (one shared set).
 __global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *scalars, uint64_t n, MsmPlan p) {
+    ZK_CHAIN_PRIO();
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t c = p.c, W = p.W;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *
 
 // offsets[k] = start of bucket k = starts[k * slices]; offsets[total] = grand total
 __global__ __launch_bounds__(256) void k_msm_compact_offsets(uint32_t *offsets, const uint32_t *starts, uint32_t total, uint32_t slices) {
+    ZK_CHAIN_PRIO();
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k <= total) offsets[k] = starts[(uint64_t)k * slices];
 }
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(256) void k_msm_compact_offsets(uint32_t *offsets, 
 
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_count(uint32_t *bin_counts, const uint32_t *codes, uint64_t total, uint32_t nbins,
                                                             uint32_t nblocks, uint32_t shift, uint32_t span) {
+    ZK_CHAIN_PRIO();
     __shared__ uint32_t hist[BIN_MAX];
     if (threadIdx.x < BIN_MAX) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_count(uint32_t *bin_counts
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint32_t *val, const uint32_t *bin_starts, const uint32_t *codes,
                                                               uint64_t total, uint32_t nbins, uint32_t nblocks, uint32_t shift, uint32_t span, uint64_t n,
                                                               uint32_t set_shift, uint32_t batch_n) {
+    ZK_CHAIN_PRIO();
     extern __shared__ uint32_t smem[];
     uint32_t *cnt = smem;                         // [BIN_MAX] per-bin count, then LDS start
     uint32_t *gdelta = smem + BIN_MAX;            // [BIN_MAX] global start - LDS start
@@ -441,6 +445,7 @@ __device__ __forceinline__ bool bin_slice_of_block(uint32_t nbins, uint32_t slic
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_count_lds(uint32_t *counts, const uint16_t *lo, const uint32_t *bin_starts,
                                                                 uint32_t nblocks, uint32_t buckets_per_bin, uint32_t nbins, uint32_t slices,
                                                                 uint32_t total_buckets) {
+    ZK_CHAIN_PRIO();
     extern __shared__ uint32_t hist[];
     uint32_t b, slice;
     if (!bin_slice_of_block(nbins, slices, b, slice)) return;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_count_lds(uint32_t *counts
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter_lds(uint32_t *entries, const uint32_t *starts, const uint16_t *lo,
                                                                   const uint32_t *val, const uint32_t *bin_starts, uint32_t nblocks,
                                                                   uint32_t buckets_per_bin, uint32_t nbins, uint32_t slices, uint32_t total_buckets) {
+    ZK_CHAIN_PRIO();
     extern __shared__ uint32_t cursor[];
     uint32_t b, slice;
     if (!bin_slice_of_block(nbins, slices, b, slice)) return;
@@ -508,6 +514,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
     return wave_off + x - v;
 }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(uint32_t *offsets, uint32_t *block_sums, const uint32_t *counts, uint32_t total) {
+    ZK_CHAIN_PRIO();
     __shared__ uint32_t lds[SCAN_BLOCK / 64];
     const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
     uint32_t v[4];
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(uint32_t *offsets, ui
     if (threadIdx.x == 0) block_sums[blockIdx.x] = bt;
 }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(uint32_t *block_sums, uint32_t nblocks, uint32_t *grand_total) {
+    ZK_CHAIN_PRIO();
     __shared__ uint32_t lds[SCAN_BLOCK / 64];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -539,6 +547,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(uint32_t *block_sums, 
     if (threadIdx.x == 0) *grand_total = carry_s;
 }
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, const uint32_t *block_sums, uint32_t total) {
+    ZK_CHAIN_PRIO();
     const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
     const uint32_t add = block_sums[blockIdx.x];
 #pragma unroll
@@ -809,6 +818,7 @@ __global__ __launch_bounds__(ZK_L1_BLOCK) ZK_G2_L1_WAVES void k_msm_accum_l1_g2s
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_accum_pair(ACCMEM *buckets, const ACCMEM *part, uint32_t *key, const uint32_t *flag,
                                                         uint32_t nlanes, uint64_t bucket_stride, uint64_t ws_stride) {
+    ZK_TAIL_PRIO();
     typedef LaneModel<F> LM;
     buckets += (uint64_t)blockIdx.y * bucket_stride;      // blockIdx.y: MSM of a batch (see k_msm_accum_l1)
     part += (uint64_t)blockIdx.y * ws_stride;
@@ -864,6 +874,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_wave(ACCMEM *buckets, const A
                                                         const uint32_t *in_flag, uint32_t nitems, ACCMEM *out_part,
                                                         uint32_t *out_key, uint32_t *out_flag, uint32_t nwaves,
                                                         uint64_t bucket_stride, uint64_t ws_stride) {
+    ZK_TAIL_PRIO();
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
     {
@@ -938,6 +949,7 @@ __global__ __launch_bounds__(256) void k_msm_accum_wave(ACCMEM *buckets, const A
 template <class F>
 __global__ __launch_bounds__(128) void k_msm_reduce_chunks(ACCMEM *scratch, const ACCMEM *buckets, uint32_t nbuckets,
                                                            uint32_t chunk, uint32_t total_chunks) {
+    ZK_TAIL_PRIO();
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
     uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LM::LPE;
@@ -971,6 +983,7 @@ static constexpr uint32_t tree_in() { return 2u * REDUCE_THREADS / LaneModel<F>:
 #define TREE_IN_MIN REDUCE_THREADS      // the smaller fan-in (G2): sizes the shared scratch formula
 template <class F>
 __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out, XYZZ<F> *out_final, const ACCMEM *in, uint32_t count, uint32_t last) {
+    ZK_TAIL_PRIO();
     extern __shared__ uint32_t lds_raw[];
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
@@ -1013,6 +1026,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out,
 template <class F>
 __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_block(ACCMEM *rec, XYZZ<F> *final_out, const ACCMEM *buckets,
                                                                          uint32_t nbuckets, uint32_t c, uint32_t nblk) {
+    ZK_TAIL_PRIO();
     extern __shared__ uint32_t lds_raw[];
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
@@ -1049,6 +1063,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_block(ACCMEM
 // the levels above the blocks, one workgroup per bucket set, on the block records in global memory
 template <class F>
 __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_bits_top(XYZZ<F> *final_out, ACCMEM *rec, uint32_t nblk, uint32_t c) {
+    ZK_TAIL_PRIO();
     typedef LaneModel<F> LM;
     typedef typename LM::R FR;
     constexpr uint32_t NE = REDUCE_THREADS / LM::LPE;

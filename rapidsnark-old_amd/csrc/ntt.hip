@@ -267,6 +267,7 @@ template <bool DIF, int LG>
 __global__ __launch_bounds__(256) void k_ntt_cross(const Fr *xb, uint64_t in_src_stride, uint64_t in_poly_stride, CrossOut out,
                                                    uint64_t out_poly_stride, uint64_t out_offset,
                                                    const TwEntry *tw, uint32_t logn, uint32_t rank, uint64_t chunk, uint64_t block) {
+    ZK_CHAIN_PRIO();
     constexpr int G = 1 << LG;
     const uint64_t op = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // offset inside this GPU's chunk
     if (op >= chunk) return;
@@ -309,6 +310,7 @@ struct ChunkDst {
 // chunk c of polynomial `poly` of this GPU's block  <->  dst.base[c] + poly*poly_stride + offset (+ position in the chunk)
 template <bool GATHER>
 __global__ __launch_bounds__(256) void k_chunk_move(ChunkDst far, Fr *blockdata, uint64_t chunk, uint64_t block, uint64_t poly_stride, uint64_t offset) {
+    ZK_CHAIN_PRIO();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element inside this GPU's block
     if (i >= block) return;
     const uint32_t poly = blockIdx.y;
@@ -399,6 +401,7 @@ void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s) {
 // h[i] = fromMontgomery(a[i]*b[i] - c[i])  (src/groth16.cpp:158-163): standard-form MSM scalars
 // blockIdx.y = vector of a batched submission (a|b|c at + y * abc_stride, h at + y * n)
 __global__ __launch_bounds__(256) void k_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, uint64_t abc_stride) {
+    ZK_CHAIN_PRIO();
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     a += (uint64_t)blockIdx.y * abc_stride;
     b += (uint64_t)blockIdx.y * abc_stride;

@@ -280,6 +280,7 @@ struct PairDev {
 // MODE 1 / 2 permute across workgroups: they read `src` and write `data`, two DIFFERENT buffers (MODE 0: the same, in place).
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_ntt_mid(Fr *data, const Fr *src, uint64_t stride_elems, PairDev t) {
+    ZK_CHAIN_PRIO();
     extern __shared__ int32_t lds[];
     typedef Fr29 F;
     // The vectors (a, b, c) of a tile run next to each other ON THE SAME XCD (workgroup i goes to XCD i mod 8, each XCD has
@@ -360,6 +361,7 @@ struct OuterDev {
 };
 template <bool DIF, int NT>
 __global__ __launch_bounds__(NT, 2) void k_ntt_outer(Fr *data, uint64_t stride_elems, OuterDev o) {
+    ZK_CHAIN_PRIO();
     extern __shared__ int32_t lds[];
     typedef Fr29 F;
     Fr *xg = data + (uint64_t)blockIdx.y * stride_elems;
