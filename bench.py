@@ -535,6 +535,12 @@ def default_depth(k, in_hbm, world=1):
     return 2 if in_hbm else 3
 
 
+def profile_order(path):
+    """profiles/<tag>_...: tags run r04a ... r04z, r04aa ... (a longer tag is a later one)"""
+    tag = os.path.basename(path).split("_")[0]
+    return (len(tag), tag)
+
+
 def traffic_from_profiles(args, config, world, which):
     """HBM bytes per launch of the roofline kernel.  NOT measured by this run: PMC counters need
     rocprofv3 around the process, so the figure is REPLAYED from the committed counter passes
@@ -545,7 +551,7 @@ def traffic_from_profiles(args, config, world, which):
         return args.traffic_bytes, "--traffic-bytes (command line)"
     import glob
     keys = ("log2n", "parallelism", "window_bits", "precomputed_window_tables")
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=profile_order, reverse=True):
         try:
             d = json.load(open(path))
             bc = d.get("bench", {}).get("config", {})
@@ -634,7 +640,7 @@ def issue_bound_from_profiles(config, world, cus, clock, ms_per_step):
     import glob
     keys = ("log2n", "parallelism", "window_bits", "precomputed_window_tables")
     instr = src = per_kernel = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_instruction_budget.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_instruction_budget.json")), key=profile_order, reverse=True):
         try:
             d = json.load(open(path))
             bc = d.get("bench_config", {})
