@@ -722,9 +722,10 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         // lanes for small circuits (see zk_prover::LaneExtra).  ZKHIP_LANES=1..8 overrides.  Eight up to 2^16 with one witness
         // per submission: a proof of that size is two chains of ~28 launches whose kernels fill a fraction of the chip each, and
         // what bounds it is how many chains run side by side (profiles/r04aj_lanes.txt: 0.72 -> 0.64 ms at 2^14, 1.16 -> 1.08 at
-        // 2^16, nothing from 2^18 on; batched submissions are SLOWER with eight: 0.39 -> 0.62 ms at 2^14 x 4).
+        // 2^16, nothing from 2^18 on; batched submissions are SLOWER with eight: 0.39 -> 0.62 ms at 2^14 x 4).  With the wave priorities
+        // in place (common.hpp) 2^17 gains too: 1.60 -> 1.53 ms; 2^18 equal, 2^19 +1.5 % (profiles/r04bm_lanes_with_priorities.txt).
         const char *e = getenv("ZKHIP_LANES");
-        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 16) && p->batch == 1 ? 8 : p->domainSize <= (1u << 22) ? 4 : 1);
+        int lanes = e ? atoi(e) : (p->domainSize <= (1u << 17) && p->batch == 1 ? 8 : p->domainSize <= (1u << 22) ? 4 : 1);
         if (lanes < 1) lanes = 1;
         if (lanes > zk_prover::MAX_LANES) lanes = zk_prover::MAX_LANES;
         if (p->part || getenv("ZKHIP_SERIAL")) lanes = 1;
