@@ -58,7 +58,7 @@ typedef struct zk_opts {
                               * circuit proved by ONE set of kernel launches (zk_prove_batch_*; small circuits, where a
                               * proof is bound by kernel latencies: DESIGN.md section 5).  Needs ZK_FLAG_PRECOMP, unsharded. */
 } zk_opts;
-#define ZK_MAX_BATCH 8
+#define ZK_MAX_BATCH 16
 
 #define ZK_FLAG_TIMINGS 1u   /* record per-stage hipEvent timings (zk_prover_timings) */
 #define ZK_FLAG_PARTITIONED_CHAIN 4u   /* sharded provers only (shard_count 2, 4 or 8): the A.w/B.w rows and the six
