@@ -273,7 +273,9 @@ template <> struct LaneModel<Fq2> {
 // No global atomics at all (the first version spent 83 % of its cycles waiting on them).  The
 // order of entries inside a bucket depends on LDS arbitration; the sum does not.
 #define CODE32_ZERO 0x7FFFFFFFu
-#define SORT_THREADS 1024u
+#ifndef SORT_THREADS
+#define SORT_THREADS 1024u      // (512 / 256 in measurement builds: workgroups that fit beside a level-1 launch's waves)
+#endif
 
 // 32-bit codes, window-major: bit 31 = sign, bits 0..30 = bucket key, 0x7FFFFFFF = zero digit.
 // key = (|d| - 1) + w * nbuckets with per-window bucket sets, |d| - 1 with window-precomputed

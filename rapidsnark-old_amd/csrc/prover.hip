@@ -1112,8 +1112,11 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     // chain it starves the chain's last pass (0.9 ms of work took 16.6 ms, profiles/r04a_lone_proof_timeline_2p22.txt), so h,
     // sort(h) and MSM H only begin when MSM A is done.  Behind the chain the starved kernel is sort(h)'s partition pass instead
     // (9.4 ms beside the G2 launch, profiles/r04b_lone_proof_timeline_2p22.txt) and the proof is no shorter: a lone proof is
-    // bound by the SUM of its chip-filling kernels, not by their order.
-    q.defer_w = lone_order(p) && !p->capturing && !p->use_graph && p->in_flight == 0 && s2 != s && !p->batch_abc;
+    // bound by the SUM of its chip-filling kernels, not by their order.  Re-measured at the end of round 4
+    // with the wave priorities in place, A|B1|C batched, and the sort's workgroups cut to 512 / 256 threads so that they fit
+    // beside a level-1 launch's waves (profiles/r04bq_lone_order_sort_workgroups.txt): 36.8 ms without, 37.0-37.4 with, and the
+    // smaller sort workgroups cost 0.7-1.5 ms by themselves.
+    q.defer_w = lone_order(p) && !p->capturing && !p->use_graph && p->in_flight == 0 && s2 != s;
     if (!q.defer_w) enqueue_witness_msms(p, c);
 
     // ---- stream: the h chain (LDS/latency-bound passes overlap with the MSMs above)
