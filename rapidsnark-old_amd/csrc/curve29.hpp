@@ -25,7 +25,7 @@ ZK_HD void madd(XYZZ<Fq29> &acc, const Affine<Fq29> &p) {
         acc = XYZZ<F>{p.x, F::carry(p.y), F::one(), F::one()};   // p.y may be a lazily negated value
         return;
     }
-    // products in PAIRS of independent chains (field29.hpp run2): (U2, S2), (PP, R2), (PPP, Q), (Y3, ZZ3); ZZZ3 is alone
+    // products in PAIRS of independent chains (field29.hpp run2): (U2, S2), (PP, R2), (PPP, Q), then ZZ3 | ZZZ3 | Y3 together
     F U2, S2;
     F::mul2(U2, p.x, acc.zz, S2, p.y, acc.zzz);
     F P = F::sub_nc(U2, acc.x);
@@ -45,8 +45,14 @@ ZK_HD void madd(XYZZ<Fq29> &acc, const Affine<Fq29> &p) {
     X3 = F::carry(X3);
     const F D = F::sub_nc(Q, X3), NY = F::neg_lazy(acc.y);
     F Y3;
+#if defined(ZK_G1_RUN2_TAIL)
     F::run2(Y3, typename F::JMulAdd2{R, D, NY, PPP}, acc.zz, typename F::JMul{acc.zz, PP});      // zz' in place: column k writes limb k-9, reads limbs >= k-8
     acc.zzz = F::mul(acc.zzz, PPP);
+#else
+    // zz' | zzz' | Y3 as three chains at once (field29.hpp run3): Y3's two products alternate with zz' first, then with zzz' —
+    // no product is left alone.  zz', zzz' in place: column k writes limb k-9 and reads limbs >= k-8.
+    F::run3(acc.zz, typename F::JMul{acc.zz, PP}, acc.zzz, typename F::JMul{acc.zzz, PPP}, Y3, typename F::JMulAdd2{R, D, NY, PPP});
+#endif
     acc.x = X3;
     acc.y = Y3;
 }
@@ -207,11 +213,15 @@ __device__ __forceinline__ void madd(XYZZ<Fq2s> &acc, const Affine<Fq2s> &p) {
         acc = XYZZ<F>{p.x, F{B::carry(p.y.v)}, F::one(), F::one()};
         return;
     }
-    // every product has an independent sibling: (U2, S2), (PP, R2), (PPP, Q), (zz', T1), (zzz', T2)
+    // products in pairs of independent chains: (U2, S2), (PP, R2), (PPP, Q), then zz' | zzz' | Y3 as three chains at once.
+    // Y3 = R*D - Y1*PPP is ONE job per lane — four operand products, one Montgomery reduction (G1's fused Y3, line 48,
+    // in the lane-pair form): re = R0 D0 - R1 D1 - y0 PPP0 + y1 PPP1, im = R0 D1 + R1 D0 - y0 PPP1 - y1 PPP0.  R and D
+    // are carried first (limbs >= -1) so that in either lane two of the four products are non-negative and two
+    // non-positive: a column holds at most 18 terms of one sign (field29.hpp JMulAdd4).
     F U2, S2;
     F::mul2(U2, p.x, acc.zz, S2, p.y, acc.zzz);
     F P{B::sub_nc(U2.v, acc.x.v)};
-    F R{B::sub_nc(S2.v, acc.y.v)};
+    F R{B::sub(S2.v, acc.y.v)};
     if (P.is_zero()) {
         if (R.is_zero()) acc = dbl_affine(Affine<F>{p.x, F{B::carry(p.y.v)}});
         else acc = XYZZ<F>::inf();
@@ -226,11 +236,15 @@ __device__ __forceinline__ void madd(XYZZ<Fq2s> &acc, const Affine<Fq2s> &p) {
 #pragma unroll
     for (int i = 0; i < 9; i++) acc.x.v.l[i] = R2.v.l[i] - PPP.v.l[i] - (Q.v.l[i] << 1);
     acc.x.v = B::carry(acc.x.v);                  // X3
-    const F D{B::sub_nc(Q.v, acc.x.v)};
-    F T1, T2;
-    F::mul2(acc.zz, pp, acc.zz, T1, F::prepare(R), D);
-    F::mul2(acc.zzz, ppp, acc.zzz, T2, ppp, acc.y);
-    acc.y = F{B::sub(T1.v, T2.v)};                // carried: keeps the next S2 - y tight
+    const B D = B::sub(Q.v, acc.x.v), Do = F::other(D);
+    const B ny = B::neg_lazy(acc.y.v), nyo = F::other(ny);
+    const F::Pre rp = F::prepare(R);
+    const B zzo = F::other(acc.zz.v), zzzo = F::other(acc.zzz.v);
+    B Y3;
+    B::run3(acc.zz.v, B::JMulAdd2{pp.a0, acc.zz.v, pp.a1s, zzo},                            // zz', zzz' in place (see the G1 madd)
+            acc.zzz.v, B::JMulAdd2{ppp.a0, acc.zzz.v, ppp.a1s, zzzo},
+            Y3, B::JMulAdd4{rp.a0, D, rp.a1s, Do, ppp.a0, ny, ppp.a1s, nyo});
+    acc.y = F{Y3};                                // a product output: limbs >= 0, the next S2 - y stays tight
 }
 #endif
 

@@ -272,27 +272,54 @@ struct Fp29 {
             y = (t & 1) ? d.l[k - i] : b.l[k - i];
         }
     };
+    struct JMulAdd4 {                   // a * b + c * d + e * f + g * h with ONE reduction (the G2 lane pair's Y3 = R*D - Y1*PPP)
+        // Column bound: 36 operand terms.  Callers keep every limb non-negative up to the carry slack ([-8, 2^29 + 8]) and
+        // arrange the signs so that two of the four products enter negated: at most 18 terms of one sign (18 * 2^58) plus the
+        // reduction terms (sum of the modulus limbs ~ 3.01 * 2^29, i.e. < 3.1 * 2^58) stay below 2^63.
+        const Fp29 &a, &b, &c, &d, &e, &f, &g, &h;
+        ZK_HD static constexpr int n(int k) { return 4 * col_n(k); }
+        ZK_HD void term(int64_t &acc, int k, int t, bool first) const {
+            int32_t x, y;
+            ops(k, t, x, y);
+            acc = first ? zk_mad0(x, y) : zk_mad(acc, x, y);
+        }
+        ZK_HD void ops(int k, int t, int32_t &x, int32_t &y) const {
+            const int i = col_lo(k) + (t >> 2), s = t & 3;
+            x = s == 0 ? a.l[i] : s == 1 ? c.l[i] : s == 2 ? e.l[i] : g.l[i];
+            y = s == 0 ? b.l[k - i] : s == 1 ? d.l[k - i] : s == 2 ? f.l[k - i] : h.l[k - i];
+        }
+    };
 #if defined(ZK_BLOCK_MAD)
     // Block form: the MADs of a column go out as a few multi-instruction asm statements (mad_blocks.inc) in which the
     // two chains alternate — one s_nop per block instead of one per MAD.  Columns are template instances (block sizes
     // must be constants where the statement is chosen).
+    template <int OFF, int N>
+    __device__ __forceinline__ static void blk_dual(int64_t &acc0, int64_t &acc1, const int32_t *x0, const int32_t *y0, const int32_t *x1, const int32_t *y1) {
+        if constexpr (N > 0) {
+            zk_blk_dvv(N < 6 ? N : 6, acc0, acc1, x0 + OFF, y0 + OFF, x1 + OFF, y1 + OFF);
+            blk_dual<OFF + 6, N - 6>(acc0, acc1, x0, y0, x1, y1);
+        }
+    }
+    template <int OFF, int N>
+    __device__ __forceinline__ static void blk_single(int64_t &acc, const int32_t *x, const int32_t *y) {
+        if constexpr (N > 0) {
+            zk_blk_svv(N < 9 ? N : 9, acc, x + OFF, y + OFF);
+            blk_single<OFF + 9, N - 9>(acc, x, y);
+        }
+    }
     template <int K, class J0, class J1>
     __device__ __forceinline__ static void col2(int64_t &acc0, int64_t &acc1, int32_t (&m0)[9], int32_t (&m1)[9], Fp29 &r0, const J0 &j0, Fp29 &r1,
                                                 const J1 &j1) {
         constexpr int n0 = J0::n(K), n1 = J1::n(K), nmin = n0 < n1 ? n0 : n1;
-        int32_t x0[18], y0[18], x1[18], y1[18];
+        int32_t x0[36], y0[36], x1[36], y1[36];
 #pragma unroll
-        for (int t = 0; t < 18; t++) {
+        for (int t = 0; t < 36; t++) {
             if (t < n0) j0.ops(K, t, x0[t], y0[t]);
             if (t < n1) j1.ops(K, t, x1[t], y1[t]);
         }
-        if constexpr (nmin > 0) zk_blk_dvv(nmin < 6 ? nmin : 6, acc0, acc1, x0, y0, x1, y1);
-        if constexpr (nmin > 6) zk_blk_dvv(nmin - 6 < 6 ? nmin - 6 : 6, acc0, acc1, x0 + 6, y0 + 6, x1 + 6, y1 + 6);
-        if constexpr (nmin > 12) zk_blk_dvv(nmin - 12, acc0, acc1, x0 + 12, y0 + 12, x1 + 12, y1 + 12);
-        if constexpr (n0 > nmin) zk_blk_svv(n0 - nmin < 9 ? n0 - nmin : 9, acc0, x0 + nmin, y0 + nmin);
-        if constexpr (n0 > nmin + 9) zk_blk_svv(n0 - nmin - 9, acc0, x0 + nmin + 9, y0 + nmin + 9);
-        if constexpr (n1 > nmin) zk_blk_svv(n1 - nmin < 9 ? n1 - nmin : 9, acc1, x1 + nmin, y1 + nmin);
-        if constexpr (n1 > nmin + 9) zk_blk_svv(n1 - nmin - 9, acc1, x1 + nmin + 9, y1 + nmin + 9);
+        blk_dual<0, nmin>(acc0, acc1, x0, y0, x1, y1);                 // both chains alternating, six MADs of each per statement
+        blk_single<nmin, n0 - nmin>(acc0, x0, y0);                     // what the longer job has left: one chain, nine per statement
+        blk_single<nmin, n1 - nmin>(acc1, x1, y1);
         constexpr int rlo = K < 9 ? 0 : K - 8, rhi = K < 9 ? K : 9, nr = rhi - rlo;
         int32_t pr[9];
 #pragma unroll
@@ -319,6 +346,54 @@ struct Fp29 {
         col2<0>(acc0, acc1, m0, m1, r0, j0, r1, j1);
         r0.l[8] = (int32_t)acc0;
         r1.l[8] = (int32_t)acc1;
+    }
+    // Three jobs at once, for a long job J2 with as many operand terms per column as J0 and J1 together (the G2 lane
+    // pair's  zz' | zzz' | Y3 = R*D - Y1*PPP): J2's chain alternates first with J0's MADs, then with J1's, so no chain runs
+    // alone for long (a column of J2 beside J0 only — 18 dependent MADs at its end — measured 2 % slower per addition).
+    template <int K, class J0, class J1, class J2>
+    __device__ __forceinline__ static void col3(int64_t &acc0, int64_t &acc1, int64_t &acc2, int32_t (&m0)[9], int32_t (&m1)[9], int32_t (&m2)[9],
+                                                Fp29 &r0, const J0 &j0, Fp29 &r1, const J1 &j1, Fp29 &r2, const J2 &j2) {
+        constexpr int n0 = J0::n(K), n1 = J1::n(K), n2 = J2::n(K);
+        static_assert(n2 == n0 + n1, "run3: the long job carries as many terms as the two short ones");
+        int32_t x0[18], y0[18], x1[18], y1[18], x2[36], y2[36];
+#pragma unroll
+        for (int t = 0; t < 36; t++) {
+            if (t < n0) j0.ops(K, t, x0[t], y0[t]);
+            if (t < n1) j1.ops(K, t, x1[t], y1[t]);
+            if (t < n2) j2.ops(K, t, x2[t], y2[t]);
+        }
+        blk_dual<0, n0>(acc0, acc2, x0, y0, x2, y2);
+        blk_dual<0, n1>(acc1, acc2, x1, y1, x2 + n0, y2 + n0);
+        constexpr int rlo = K < 9 ? 0 : K - 8, rhi = K < 9 ? K : 9, nr = rhi - rlo;
+        int32_t pr[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if (i < nr) pr[i] = PS(K - (rlo + i));
+        if constexpr (nr > 0) zk_blk_tmp(nr < 6 ? nr : 6, acc0, acc1, acc2, m0 + rlo, m1 + rlo, m2 + rlo, pr);
+        if constexpr (nr > 6) zk_blk_tmp(nr - 6, acc0, acc1, acc2, m0 + rlo + 6, m1 + rlo + 6, m2 + rlo + 6, pr + 6);
+        if constexpr (K < 9) {
+            m0[K] = mont_m(acc0);
+            m1[K] = mont_m(acc1);
+            m2[K] = mont_m(acc2);
+            zk_blk_tmp1(acc0, acc1, acc2, m0[K], m1[K], m2[K], PS(0));
+        } else {
+            r0.l[K - 9] = out_limb(acc0);
+            r1.l[K - 9] = out_limb(acc1);
+            r2.l[K - 9] = out_limb(acc2);
+        }
+        acc0 >>= 29;
+        acc1 >>= 29;
+        acc2 >>= 29;
+        if constexpr (K < 16) col3<K + 1>(acc0, acc1, acc2, m0, m1, m2, r0, j0, r1, j1, r2, j2);
+    }
+    template <class J0, class J1, class J2>
+    __device__ __forceinline__ static void run3(Fp29 &r0, const J0 &j0, Fp29 &r1, const J1 &j1, Fp29 &r2, const J2 &j2) {
+        int64_t acc0 = 0, acc1 = 0, acc2 = 0;
+        int32_t m0[9], m1[9], m2[9];
+        col3<0>(acc0, acc1, acc2, m0, m1, m2, r0, j0, r1, j1, r2, j2);
+        r0.l[8] = (int32_t)acc0;
+        r1.l[8] = (int32_t)acc1;
+        r2.l[8] = (int32_t)acc2;
     }
 #else
     template <class J0, class J1>
@@ -352,6 +427,12 @@ struct Fp29 {
         }
         r0.l[8] = (int32_t)acc0;
         r1.l[8] = (int32_t)acc1;
+    }
+    template <class J0, class J1, class J2>
+    ZK_HD static void run3(Fp29 &r0, const J0 &j0, Fp29 &r1, const J1 &j1, Fp29 &r2, const J2 &j2) {     // (host pass / C builds)
+        Fp29 t2 = run1(j2);
+        run2(r0, j0, r1, j1);
+        r2 = t2;
     }
 #endif
     template <class J>

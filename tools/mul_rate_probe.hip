@@ -7,13 +7,21 @@
 #include <stdio.h>
 using namespace zk;
 
-template <int MODE>      // 0: x = mul(x, y)   1: two lone products per iteration   2: mul2 (interleaved pair)   3: G1 madd
+template <int MODE>      // 0: x = mul(x, y)   1: two lone products per iteration   2: mul2 (interleaved pair)   3: G1 madd   4: G2 madd, Fq2 split across a lane pair
 __global__ __launch_bounds__(256) void k_loop(uint32_t *out, const Affine<Fq> *pts, uint32_t iters) {
     typedef Fq29 FR;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     Affine<FR> P0 = load_affine(pts + (t & 1023u)), P1 = load_affine(pts + ((t + 7u) & 1023u));
     uint32_t x = 0;
-    if (MODE == 3) {
+    if (MODE == 4) {
+        Affine<Fq2s> Q0{Fq2s{P0.x}, Fq2s{P0.y}}, Q1{Fq2s{P1.x}, Fq2s{P1.y}};
+        XYZZ<Fq2s> acc{Fq2s{P1.x}, Fq2s{P1.y}, Fq2s::one(), Fq2s::one()};
+        for (uint32_t i = 0; i < iters; i++) {
+            madd(acc, (i & 1u) ? Q1 : Q0);
+            Q0.x.v.l[0] ^= (int32_t)(i & 3u);
+        }
+        for (int k = 0; k < 9; k++) x ^= (uint32_t)(acc.x.v.l[k] ^ acc.y.v.l[k] ^ acc.zz.v.l[k] ^ acc.zzz.v.l[k]);
+    } else if (MODE == 3) {
         XYZZ<FR> acc = XYZZ<FR>::from_affine(P1);
         for (uint32_t i = 0; i < iters; i++) {
             madd(acc, (i & 1u) ? P1 : P0);
@@ -75,9 +83,9 @@ int main() {
     for (int wps = 1; wps <= 3; wps++) {
         const int blocks = cus * wps;
         const double f = 1e-3 * ghz * 1e9 / ((double)iters * wps);
-        printf("%d wave(s)/SIMD: cycles per wave-level product: lone %.0f | two lone per iteration %.0f | interleaved pair %.0f ; G1 mixed addition %.0f cycles\n", wps,
+        printf("%d wave(s)/SIMD: cycles per wave-level product: lone %.0f | two lone per iteration %.0f | interleaved pair %.0f ; G1 mixed addition %.0f cycles ; G2 mixed addition (lane pair) %.0f cycles\n", wps,
                run(k_loop<0>, blocks, out, pts, iters) * f, run(k_loop<1>, blocks, out, pts, iters) * f / 2, run(k_loop<2>, blocks, out, pts, iters) * f / 2,
-               run(k_loop<3>, blocks, out, pts, iters) * f);
+               run(k_loop<3>, blocks, out, pts, iters) * f, run(k_loop<4>, blocks, out, pts, iters) * f);
     }
     return 0;
 }
