@@ -1,40 +1,25 @@
 #!/usr/bin/env python
-"""bench.py — Groth16 prove() throughput on MI355X (BASELINE.json metric).
+"""bench.py — Groth16 prove() throughput on MI355X (BASELINE.json metric: proofs/s and ms/proof at 2^20 and 2^22).
 
-A "step" is one whole proof (src/groth16.cpp:48-254) of a synthetic BN254 data set with
-n = domainSize = nVars = 2^k (default k = 22: BASELINE configs[2], the largest single-GPU
-configuration and the one the 10x target is quoted on; --log2n 20 gives configs[1]).
-Every step has its own witness (distinct per step while they fit 8 GiB of host memory: 33 x 128 MiB at
-2^22; `config.distinct_witnesses` says how many were made) in HOST memory (pageable numpy arrays), as the
-reference's Prover::prove(FrElement *wtns) contract has it (src/groth16.hpp:101,
-src/main_prover.cpp:74-75): the upload of every witness is INSIDE the timed region
-(zk_prove_submit stages it through pinned memory on a stream of its own, so that it overlaps
-the previous proof).  The rate with witnesses already resident in HBM is measured too and
-reported as the extra key `resident_witness` (--witness-in hbm makes it the headline again).
+A "step" is one whole proof (reference src/groth16.cpp:48-254) of a synthetic BN254 key with n = domainSize = nVars = 2^k
+(default k = 22: BASELINE configs[2]; --log2n 20 = configs[1]).  Every step has its own witness in pageable HOST memory, as
+the reference's Prover::prove(FrElement *wtns) contract has it (src/groth16.hpp:101): the upload is INSIDE the timed region
+(zk_prove_submit).  The rate with witnesses resident in HBM is measured too (`resident_witness`).
 
-  python bench.py --gpus 1 --steps K --warmup W                      (N = 1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus 1 --steps K --warmup W                                  (N = 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1: one proof split across the ranks,
+      MSM tables sharded by point range, the chain partitioned, four RCCL all_to_all per proof; "scaling": "strong")
 
-N > 1: one process per GPU; every MSM point table is sharded by index range and the
-chain (A.w/B.w rows + the six transforms) is PARTITIONED the same way when N is 2, 4 or 8: rank g
-holds block g of a, b, c, h, runs the local stages itself and meets the others in the log2(N) top
-stages through four rounds of RCCL all_to_all per proof (2 x (N-1)/N of a block per transform over
-xGMI; rapidsnark_old_amd.dist.ShardedChain).  The MSM results are exchanged by one all_gather of
-the 384-byte partial-sum record; rank 0 adds the partials and does the O(1) final assembly.
---chain replicated keeps the round-1 behaviour (every rank runs the whole chain, no all_to_all).
-One proof is split across the ranks => "scaling": "strong".
-
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel BY TOTAL TIME: the G1 bucket
-accumulation k_msm_accum_l1<Fq>, four launches per proof, algorithmic bytes 96*n per launch,
-SURVEY §8d; the longest single launch, the G2 accumulation, is reported under `also`) and, at
-N = 1, `cpu_baseline` (the C restatement of rapidsnark's CPU algorithm, oracle/, timed on the
-host cores: one warm-up, then the median of as many full proofs as the budget holds).
-BASELINE's metric is quoted "at 2^20 and 2^22": the default N = 1 run therefore also times the 2^20 member of the
-family (configs[1]) the same way and reports it under `also_2p20` (own ms_per_step, synchronous ms/proof and G1-launch
-roofline fraction; --no-2p20 skips it, and so do --no-cpu and the other non-default workloads: A/B and profiling runs
-want one size).  `ms_per_proof_sync` is SURVEY section 8(d)'s definition of ms/proof: ONE
-synchronous zk_prove with the witness in host memory (the reference's main_prover.cpp:75), next to the pipelined period
-`ms_per_step`.  N > 1 prints `rccl_ranks` and the mean GPU time of each all_to_all / all_gather phase (`exchange_ms`).
+ONE JSON line on rank 0.  Besides the contract's keys:
+  roofline      flat: the dominant kernel k_msm_accum_l1<Fq> against HBM (algorithmic bytes 96*n per G1 MSM / launch time, SURVEY
+                section 8d), its measured HBM traffic and random-gather rate against the chip's gather ceiling, the G2 launch (g2_*),
+                and the path's own bound — VALU issue (issue_*: instructions per proof x 4 cycles / (SIMDs x sampled clock)).
+                Counters come from rocprofv3 passes the bench runs itself after the timed legs (rapidsnark_old_amd.counters),
+                or are replayed from profiles/ when it cannot: `traffic_source` says which.
+  cpu_baseline  the C restatement of rapidsnark's CPU algorithm (oracle/) timed on this box's host cores, generic and ADX builds.
+  also_2p20, also_realistic, (also_server)   the other configurations of BASELINE's metric, timed by the same code.
+  summary       LAST in the line: every scalar DESIGN.md quotes, so that a record keeping only the tail of stdout holds them.
+Definitions of every field: DESIGN.md section 6.
 """
 import argparse
 import json
@@ -88,39 +73,64 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-2p20", action="store_true", help="skip the also_2p20 leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--cpu-budget-s", type=float, default=36.0)
-    ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run")
+    ap.add_argument("--no-counters", action="store_true", help="do not run the rocprofv3 counter passes after the timed legs (replay profiles/ instead)")
+    ap.add_argument("--no-server", action="store_true", help="skip the also_server leg of a default run (proverServer over REST on a Semaphore-class key)")
+    ap.add_argument("--counters-child", default="", help=argparse.SUPPRESS)      # internal: the process rocprofv3 wraps (rapidsnark_old_amd.counters)
+    ap.add_argument("--counters-proofs", type=int, default=2, help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+LEG_OF = {("dense", 22): "2p22", ("circuit", 22): "2p22_circuit", ("dense", 20): "2p20"}      # legs of a default run that get counters
 
 
 def main():
     args = parse()
+    if args.counters_child:
+        counters_child(args)
+        return
     out = run(args)
     if out is None:                       # ranks > 0
         return
     default_run = args.gpus == 1 and args.log2n == 22 and not args.no_cpu and args.batch <= 1 and args.witness == "uniform" and args.shape == "dense"
+    legs = {LEG_OF.get((args.shape, args.log2n), "headline"): out}
+    import copy
     if default_run and not args.no_realistic:
         # what a REAL circom key and witness look like to the prover (BASELINE configs[4]'s fidelity; SURVEY section 8d's
         # secondary line): the circuit-shaped member of the family with the 80/15/5 witness, timed the same way by the same code
-        import copy
         a3 = copy.copy(args)
-        a3.witness, a3.shape, a3.no_cpu, a3.no_2p20, a3.no_realistic, a3.in_flight = "realistic", "circuit", True, True, True, 0
-        o3 = run(a3)
-        out["also_realistic"] = {kk: o3[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "resident_witness",
-                                                        "latency_ms_one_at_a_time", "stage_ms") if kk in o3}
-        out["also_realistic"]["note"] = ("same 2^22 domain; nVars = 3/4 n + 5, 3 public signals, ~30 % of the rows of A and of B1/B2 at infinity, witness 80 % in "
-                                         "{0,1} / 15 % < 2^32 / 5 % full-size: the MSM H and the six transforms cost what they cost in the headline, the four "
-                                         "witness MSMs shrink to their non-zero digits")
+        a3.witness, a3.shape, a3.no_cpu, a3.in_flight = "realistic", "circuit", True, 0
+        legs["2p22_circuit"] = run(a3)
     if default_run and not args.no_2p20:
         # BASELINE's metric is quoted "at 2^20 and 2^22": configs[1], timed the same way by the same code
-        import copy
         a2 = copy.copy(args)
-        a2.log2n, a2.no_cpu, a2.no_2p20, a2.in_flight = 20, True, True, 0
-        o2 = run(a2)
-        out["also_2p20"] = {kk: o2[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "resident_witness",
-                                                   "latency_ms_one_at_a_time", "stage_ms") if kk in o2}
-        r2 = o2["roofline"]
-        out["also_2p20"]["roofline"] = {kk: r2[kk] for kk in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms", "algorithmic_bytes",
-                                                              "launch_ms_one_proof_in_flight", "frac_one_proof_in_flight", "issue_bound", "whole_proof")}
+        a2.log2n, a2.no_cpu, a2.in_flight = 20, True, 0
+        legs["2p20"] = run(a2)
+    # ---- counters: measured by this run where rocprofv3 can wrap a child of it, else replayed from profiles/
+    from rapidsnark_old_amd import counters
+    measured, how = {}, None
+    why_not = counters.available() if not args.no_counters else "--no-counters"
+    can = [leg for leg in legs if leg in LEG_OF.values()]
+    if why_not is None and args.gpus == 1 and can:
+        try:
+            measured, how = counters.measure(can, os.path.abspath(__file__), precomp=args.precomp, proofs=args.counters_proofs)
+        except Exception as exc:           # noqa: BLE001  (a failed pass must not cost the line)
+            why_not = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+    for leg, o in legs.items():
+        if leg in measured:
+            cs, src = measured[leg], how
+        else:
+            cs, src = counters.replay(o["config"], o["n_gpus"])
+            if why_not:
+                src += "; in-run passes skipped: " + why_not
+        finish_roofline(o, cs, src, counters.gather_ceiling(64, o["roofline"]["gather_table_bytes"]))
+    for leg, key in (("2p22_circuit", "also_realistic"), ("2p20", "also_2p20")):
+        if leg in legs and legs[leg] is not out:
+            o = legs[leg]
+            out[key] = {kk: o[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "roofline", "resident_witness",
+                                             "latency_ms_one_at_a_time", "stage_ms") if kk in o}
+    if default_run and not args.no_server:
+        out["also_server"] = server_leg()
+    out["summary"] = summary_of(out)            # LAST: the scalars DESIGN.md quotes, within the tail of the line
     print(json.dumps(out), flush=True)
 
 
@@ -170,6 +180,11 @@ def run(args):
                             window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned,
                             batch=args.batch if world == 1 else 0, sparse_witness=sparse)
     t_create = time.time() - t0
+    plan = prover.info()                    # zk_prover_info: what the library decided (windows, A|B1|C in one launch, lanes, depths)
+
+    def depth_for(in_hbm):
+        return args.in_flight or plan["depth_resident_witness" if in_hbm else "depth_host_witness"]
+
     chain = None
     sliced_upload = False
     if partitioned:
@@ -254,7 +269,7 @@ def run(args):
         if pipelined and warmup:
             # still untimed: fill the pipeline once, so that every proof slot the timed loop uses exists (a slot's
             # buffers are allocated the first time its depth is reached)
-            depth0 = args.in_flight or default_depth(k, in_hbm, world)
+            depth0 = depth_for(in_hbm)
             for i in range(depth0):
                 submit(i)
             for i in range(depth0):
@@ -270,7 +285,7 @@ def run(args):
             # i is collected, so its sort, SpMV and NTTs overlap proof i's reductions, D2H and host tail;
             # with host witnesses a third proof hides the upload (a proof cannot start before its witness
             # has arrived, and a slot is only free again after a collect)
-            depth = args.in_flight or default_depth(k, in_hbm, world)
+            depth = depth_for(in_hbm)
             if world == 1 and args.collector_thread:
                 # two host threads, as a server would run them: this one submits, the other collects (wait for
                 # the GPU + 0.3 ms of host tail per proof: window sums, final assembly).  The
@@ -407,73 +422,57 @@ def run(args):
         return None
 
     ms_per_step = elapsed / args.steps * 1e3
-    # dominant kernel BY TOTAL TIME: k_msm_accum_l1<Fq> — the G1 bucket accumulation, four launches per
-    # proof (MSM A, B1, C, H; 47 % of a proof's VALU instructions).  Duration: hipEvents recorded by the
-    # library on the kernel's own stream immediately before/after the launch of MSM A (the other
-    # streams' kernels share the chip meanwhile).  Algorithmic bytes: 96 per point (64 B affine point
-    # + 32 B scalar, SURVEY §8d "one G1 MSM = 96*n").  `also`: the longest single launch, the G2
-    # accumulation of MSM B2 (160 B per point).
     shape_txt = ("domainSize=nVars=2^%d, nPublic=1" % k) if args.shape == "dense" else \
         ("domainSize=2^%d, nVars=%d, nPublic=%d, ~30%% of the rows of A and of B1/B2 at infinity" % (k, wl["nVars"], wl["nPublic"]))
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (%s, nCoefs=%d), %s witness" % (k, shape_txt, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80% {0,1}, 15% <2^32, 5% full)"),
-              "shape": args.shape,
-              "log2n": k, "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")), "window_bits": args.window_bits or plan_window_bits(n, world, bool(args.precomp)),
-              "precomputed_window_tables": bool(args.precomp), "witness_msm_window_bits": 16 if (sparse and k > 18) else None, "proofs_in_flight": (args.in_flight or default_depth(k, headline_hbm, world)) if pipelined else 1,
+              "shape": args.shape, "log2n": k,
+              "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")),
+              "window_bits": plan["window_bits_h"], "windows": plan["windows_h"], "precomputed_window_tables": bool(plan["precomputed_tables"]),
+              "witness_msm_window_bits": plan["window_bits_w"] if plan["window_bits_w"] != plan["window_bits_h"] else None,
+              "msm_a_b1_c_in_one_launch": bool(plan["msm_a_b1_c_one_launch"]), "lanes": plan["lanes"],
+              "proofs_in_flight": depth_for(headline_hbm) if pipelined else 1,
               "witnesses_per_submission": args.batch if (args.batch > 1 and world == 1 and not headline_hbm) else 1,
               "host_threads": 2 if (pipelined and world == 1 and args.collector_thread) else 1,
-              "witness": "resident in HBM before the timed region" if headline_hbm else "pageable host memory; upload inside the timed region (zk_prove_submit)",
+              "witness": "hbm-resident" if headline_hbm else "host-pageable, upload timed",
               "witness_upload": ("each rank uploads 1/N over PCIe, all_gather over xGMI" if sliced_upload else "whole witness per rank") if world > 1 else "whole witness",
-              "distinct_witnesses": "%d for %d steps + %d warm-up%s" % (len(wits_host), args.steps, args.warmup, "" if len(wits_host) >= nw else " (cycled)")}
-    batched_abc = batch_abc_default(-(-wl["nVars"] // world), world)
-    config["msm_a_b1_c_in_one_launch"] = batched_abc
+              "distinct_witnesses": len(wits_host)}
+    # Dominant kernel by instructions and by exclusive time: k_msm_accum_l1<Fq>, the G1 bucket accumulation of MSM A, B1, C, H.
+    # launch_ms = its time PER G1 MSM (hipEvents on the kernel's own stream around every launch, summed over a proof, / 4): the
+    # unit of the 96*n algorithmic bytes (64 B point + 32 B scalar), whatever the number of launches the four MSMs share.
     g1_ms, g2_ms = stage["g1_l1_kernel"], stage["g2_l1_kernel"]
-    pts_per_launch = n / world
-    alg_bytes = G1_MSM_BYTES_PER_POINT * pts_per_launch
-    achieved = alg_bytes / (g1_ms * 1e-3) / 1e9
-    traffic, traffic_src = traffic_from_profiles(args, config, world, "g1")
-    traffic2, _ = traffic_from_profiles(args, config, world, "g2")
-    issue = issue_bound_from_profiles(config, world, torch.cuda.get_device_properties(local_rank).multi_processor_count, clock.summary(), ms_per_step)
-    roofline = {"bound": "hbm", "kernel": "k_msm_accum_l1<Fq> (G1 bucket accumulation; 4 launches per proof: MSM A, B1, C, H — the dominant kernel by VALU "
-                                          "instructions (46 % of a proof's) and by exclusive time (4 launches of ~3.8 ms alone out of a ~33 ms period))",
-                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "launch_ms": round(g1_ms, 4), "msms_per_proof": 4, "launches_per_proof": 2 if batched_abc else 4, "algorithmic_bytes": alg_bytes,
-                "launch_ms_definition": "time of the kernel per G1 MSM (algorithmic_bytes each): the sum of the kernel's launch durations of a proof / 4"
-                                        + (" — MSM A, B1 and C are ONE launch over three point tables (blockIdx.y; 3 x algorithmic_bytes), MSM H another: in a "
-                                           "rocprofv3 kernel table of the leg, launch_ms = TotalDurationNs of k_msm_accum_l1<Fq> / (4 x proofs of the leg)" if batched_abc else ""),
-                "launch_sharing": "launch_ms is the mean over the timed region, where a launch shares the chip with the kernels of the other proofs in flight "
-                                  "(config.proofs_in_flight): more in flight raises proofs/s and LOWERS this fraction; launch_ms_one_proof_in_flight is the same "
-                                  "launch with one proof at a time (it still runs beside that proof's own G2 launch), measured after the timed region",
-                "launch_ms_one_proof_in_flight": round(lone["g1_l1_kernel"], 4) if lone else None,
-                "frac_one_proof_in_flight": round(alg_bytes / (lone["g1_l1_kernel"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if lone else None,
-                "also": {"kernel": "k_msm_accum_l1_g2s (G2 bucket accumulation of MSM B2, Fq2 split across lane pairs; the longest single launch)",
-                         "launch_ms": round(g2_ms, 4), "algorithmic_bytes": G2_MSM_BYTES_PER_POINT * pts_per_launch,
-                         "achieved": round(G2_MSM_BYTES_PER_POINT * pts_per_launch / (g2_ms * 1e-3) / 1e9, 3),
-                         "frac": round(G2_MSM_BYTES_PER_POINT * pts_per_launch / (g2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic2},
-                "issue_bound": issue,
-                "whole_proof": {"algorithmic_bytes": 1424 * n, "achieved": round(1424 * n / (ms_per_step * 1e-3) / 1e9, 2),
-                                "frac": round(1424 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                "note": "B_alg = 1424*n bytes per proof (SURVEY §8d) over the measured period"}}
+    pts = n / world
+    alg1, alg2 = G1_MSM_BYTES_PER_POINT * pts, G2_MSM_BYTES_PER_POINT * pts
+    ck = clock.summary()
+    roofline = {"bound": "hbm", "kernel": "k_msm_accum_l1<Fq>", "achieved": round(alg1 / (g1_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg1 / (g1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "traffic_source": None, "traffic_ratio": None,
+                "launch_ms": round(g1_ms, 4), "algorithmic_bytes": int(alg1), "msms_per_proof": 4, "launches_per_proof": 2 if plan["msm_a_b1_c_one_launch"] else 4,
+                "launch_ms_one_in_flight": round(lone["g1_l1_kernel"], 4) if lone else None,
+                "frac_one_in_flight": round(alg1 / (lone["g1_l1_kernel"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if lone else None,
+                "g2_kernel": "k_msm_accum_l1_g2s", "g2_launch_ms": round(g2_ms, 4), "g2_launch_ms_one_in_flight": round(lone["g2_l1_kernel"], 4) if lone else None,
+                "g2_algorithmic_bytes": int(alg2), "g2_frac": round(alg2 / (g2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                "clock_ghz": ck.get("clock_ghz"), "power_w": ck.get("power_w"), "clock_samples": ck.get("samples"),
+                "simds": torch.cuda.get_device_properties(local_rank).multi_processor_count * 4,
+                # what the kernel's largest launch gathers from: W rows of 64 B per point of every table the launch walks
+                "gather_table_bytes": int((3 if plan["msm_a_b1_c_one_launch"] else 1) * (plan["windows_h"] if plan["precomputed_tables"] else 1) * pts * 64),
+                "whole_proof_algorithmic_bytes": 1424 * n, "whole_proof_frac": round(1424 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
 
     out = {
         "metric": "Groth16 proofs/sec", "value": round(args.steps / elapsed, 4), "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32/i64 (BN254 Fr/Fq in 9x29-bit signed limbs, 64-bit v_mad_i64_i32 column accumulators)",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i64 (v_mad_i64_i32 column sums over 9x29-bit signed limbs, BN254 Fr/Fq)",
         "data": "synthetic",
         "config": config,
         "roofline": roofline,
         "stage_ms": {kk: round(v, 3) for kk, v in stage.items()},
         "setup_s": {"generate": round(t_gen, 2), "create": round(t_create, 2)},
     }
-    other = {"value": round(args.steps / other_elapsed, 4), "unit": "proofs/s", "ms_per_step": round(other_elapsed / args.steps * 1e3, 3),
-             "steps": args.steps, "note": "same K proofs, timed the same way, outside the headline's timed region"}
+    other = {"value": round(args.steps / other_elapsed, 4), "unit": "proofs/s", "ms_per_step": round(other_elapsed / args.steps * 1e3, 3), "steps": args.steps}
     out["host_witness" if headline_hbm else "resident_witness"] = other
     if verified is not None:
         out["multi_gpu_proof_equals_single_gpu_proof"] = verified
     if latency_ms is not None:
         out["latency_ms_one_at_a_time"] = {"witness_in_hbm": round(latency_ms, 3), "witness_in_host_memory": round(latency_host_ms, 3)}
-        # SURVEY section 8(d)'s ms/proof: one synchronous zk_prove, witness in host RAM, nothing else on the GPU
-        out["ms_per_proof_sync"] = round(latency_host_ms, 3)
+        out["ms_per_proof_sync"] = round(latency_host_ms, 3)       # SURVEY 8(d)'s ms/proof: one synchronous zk_prove, witness in host RAM
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, k, synth, prover, wits_host[0], wits_dev[0], args.cpu_budget_s)
     if world > 1:
@@ -490,11 +489,98 @@ def run(args):
     return out
 
 
+def finish_roofline(out, cs, source, ceiling):
+    """Counter-derived fields of one leg's roofline (cs: rapidsnark_old_amd.counters summary or None): HBM traffic per G1 MSM and its
+    ratio to the algorithmic bytes, the random-gather rate of the one-in-flight launch against the chip's ceiling for 64-byte
+    bursts (tools/gather_probe, committed), and the path's own bound — VALU issue at 4 cycles per wave-level instruction."""
+    r = out["roofline"]
+    r["traffic_source"] = source
+    cs = cs or {}
+    t1 = cs.get("g1_hbm_bytes_per_msm")
+    r["traffic"] = t1
+    r["traffic_ratio"] = round(t1 / r["algorithmic_bytes"], 3) if t1 else None
+    r["g2_traffic"] = cs.get("g2_hbm_bytes_per_launch")
+    r["transforms_traffic_per_proof"] = cs.get("transforms_hbm_bytes_per_proof")
+    lm = r.get("launch_ms_one_in_flight")
+    r["gather_bytes_per_s"] = round(t1 / (lm * 1e-3)) if (t1 and lm) else None
+    r["gather_ceiling_bytes_per_s"] = round(ceiling["bytes_per_s"]) if ceiling else None
+    r["gather_ceiling_source"] = ("%s: 64-B rows, %d MB table, best access pattern" % (ceiling["source"], ceiling["table_mb"])) if ceiling else None
+    r["gather_frac"] = round(r["gather_bytes_per_s"] / ceiling["bytes_per_s"], 4) if (ceiling and r["gather_bytes_per_s"]) else None
+    instr = cs.get("valu_instructions_per_proof")
+    r["valu_instructions_per_proof"] = instr
+    r["cycles_per_instruction"] = 4.0
+    r["g1_valu_per_msm"], r["g2_valu_per_launch"], r["transforms_valu_per_proof"] = cs.get("g1_valu_per_msm"), cs.get("g2_valu_per_launch"), cs.get("transforms_valu_per_proof")
+    ghz = r.get("clock_ghz")
+    r["issue_bound_ms"] = round(instr * 4.0 / (r["simds"] * ghz * 1e9) * 1e3, 3) if (instr and ghz) else None
+    r["issue_frac"] = round(r["issue_bound_ms"] / out["ms_per_step"], 4) if r["issue_bound_ms"] else None
+
+
+def summary_of(out):
+    """The scalars DESIGN.md section 6 quotes, flat and LAST in the line."""
+    r = out["roofline"]
+    s = {"proofs_per_s": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_proof_sync": out.get("ms_per_proof_sync"),
+         "ms_per_step_resident": out.get("resident_witness", {}).get("ms_per_step"),
+         "roofline_frac": r["frac"], "roofline_frac_one_in_flight": r.get("frac_one_in_flight"), "g1_launch_ms": r["launch_ms"],
+         "g1_launch_ms_one_in_flight": r.get("launch_ms_one_in_flight"), "g2_launch_ms": r["g2_launch_ms"], "g2_launch_ms_one_in_flight": r.get("g2_launch_ms_one_in_flight"),
+         "traffic_ratio": r.get("traffic_ratio"), "gather_frac": r.get("gather_frac"), "whole_proof_frac": r["whole_proof_frac"],
+         "valu_instructions_per_proof": r.get("valu_instructions_per_proof"), "issue_bound_ms": r.get("issue_bound_ms"), "issue_frac": r.get("issue_frac"),
+         "clock_ghz": r.get("clock_ghz"), "power_w": r.get("power_w"),
+         "counters": "measured in this run" if str(r.get("traffic_source", "")).startswith("measured") else "replayed"}
+    for key, tag in (("also_2p20", "2p20"), ("also_realistic", "realistic")):
+        o = out.get(key)
+        if o:
+            s["ms_per_step_" + tag], s["proofs_per_s_" + tag], s["ms_per_proof_sync_" + tag] = o["ms_per_step"], o["value"], o.get("ms_per_proof_sync")
+            s["issue_frac_" + tag] = o["roofline"].get("issue_frac")
+    c = out.get("cpu_baseline")
+    if c:
+        s["cpu_proofs_per_s"], s["cpu_cores"], s["cpu_variant"] = c["value"], c["cores"], c.get("variant")
+        s["gpu_over_cpu"] = round(out["value"] / c["value"], 1) if c["value"] else None
+        s["gpu_proof_bit_exact_vs_cpu"] = c.get("gpu_proof_bit_exact_vs_cpu")
+    sv = out.get("also_server")
+    if sv:
+        s["server_proofs_per_s"] = sv.get("value")
+    return s
+
+
+def counters_child(args):
+    """The process rocprofv3 --pmc wraps (rapidsnark_old_amd.counters.run_pass): for every leg, a prover of that configuration,
+    a begin marker, one warm-up + `--counters-proofs` synchronous proofs with the witness resident, an end marker."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    import torch
+    import rapidsnark_old_amd as zk
+    from rapidsnark_old_amd import synth, counters
+    legs = [x for x in args.counters_child.split(",") if x]
+    spec = {v: kk for kk, v in LEG_OF.items()}
+    for i, leg in enumerate(legs, 1):
+        shape, k = spec[leg]
+        realistic = shape == "circuit"
+        wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes(), shape=shape)
+        p = ProverFromView(zk, wl, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=bool(args.precomp),
+                           sparse_witness=realistic and bool(args.precomp))
+        w = torch.from_numpy(synth.make_witness(k, seed=1, kind="realistic" if realistic else "uniform", n_vars=wl["nVars"])).cuda()
+        torch.cuda.synchronize()
+        marker(zk, torch, counters.MARK_BEGIN + i)
+        for _ in range(1 + args.counters_proofs):
+            p.prove_dev(w.data_ptr())
+        marker(zk, torch, counters.MARK_END + i)
+        p.lib.zk_prover_destroy(p.h)
+        del w, wl
+    print("[counters-child] done", flush=True)
+
+
+def marker(zk, torch, workgroups):
+    """A recognisable launch: zk_fr_mul_vec over 256 x workgroups elements = a k_mul_vec<Fr> grid of that many workgroups."""
+    torch.cuda.synchronize()
+    a = np.zeros(32 * 256 * workgroups, dtype=np.uint8)
+    zk.fr_mul_vec(a, a)
+    torch.cuda.synchronize()
+
+
 def replicas_leg(zk, wl, device, k, wits_host, steps, precomp, dist, xdev, torch, world):
     """N > 1: K proofs per GPU on N independent unsharded provers (host witnesses, the default number in flight, one host
     thread per rank) -> the line's `replicas` object.  Weak scaling: per-GPU work is fixed as N grows."""
     p = ProverFromView(zk, wl, device=device, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=precomp)
-    depth = default_depth(k, False, 1)
+    depth = p.info()["depth_host_witness"]
     for i in range(depth):                      # untimed: every proof slot exists afterwards
         p.submit_host(wits_host[i % len(wits_host)])
     for i in range(depth):
@@ -522,53 +608,6 @@ def replicas_leg(zk, wl, device, k, wits_host, steps, precomp, dist, xdev, torch
             "proofs_in_flight_per_gpu": depth,
             "note": "every GPU proves its own proofs on an unsharded prover (no collective in the data path; proverServer's throughput mode); "
                     "the headline above is ONE proof at a time across all GPUs (north_star: MSMs and NTT partitioned)"}
-
-
-def default_depth(k, in_hbm, world=1):
-    """Proofs in flight per GPU: large circuits saturate the chip with two (three when the witness upload has to be
-    hidden); below 2^19 a proof is bound by the serial latency of its ~80 small kernels and more in flight fills the GPU."""
-    if k < 19:
-        return 8
-    if k <= 22 and world == 1:          # four lanes of streams per prover up to 2^22 (csrc/prover.hip): 2^20 11.1 -> 10.2 ms with six in
-        return 6                            # flight; 2^22: four / five / six in flight 33.5 / 32.6 / 32.5 ms with host witnesses (r03 A/B, three
-                                            # alternations), resident unchanged at 32.5: the deeper pipeline hides the 128 MiB upload completely
-    return 2 if in_hbm else 3
-
-
-def profile_order(path):
-    """profiles/<tag>_...: tags run r04a ... r04z, r04aa ... (a longer tag is a later one)"""
-    tag = os.path.basename(path).split("_")[0]
-    return (len(tag), tag)
-
-
-def traffic_from_profiles(args, config, world, which):
-    """HBM bytes per launch of the roofline kernel.  NOT measured by this run: PMC counters need
-    rocprofv3 around the process, so the figure is REPLAYED from the committed counter passes
-    (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of this same command;
-    profiles/*_pmc_traffic.json) when they were taken on this exact configuration (same workload,
-    window bits, table mode, GPU count); else null.  Returns (bytes | None, source string)."""
-    if args.traffic_bytes is not None and which == "g1":
-        return args.traffic_bytes, "--traffic-bytes (command line)"
-    import glob
-    keys = ("log2n", "parallelism", "window_bits", "precomputed_window_tables")
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=profile_order, reverse=True):
-        try:
-            d = json.load(open(path))
-            bc = d.get("bench", {}).get("config", {})
-            if all(bc.get(kk) == config.get(kk) for kk in keys) and bc.get("shape", "dense") == config.get("shape") and d.get("bench", {}).get("n_gpus") == world:
-                for name, v in d["kernels"].items():
-                    is_g2 = "k_msm_accum_l1_g2s" in name or ("k_msm_accum_l1" in name and "Fp2T" in name)
-                    is_g1 = "k_msm_accum_l1" in name and not is_g2
-                    if (which == "g2" and is_g2) or (which == "g1" and is_g1):
-                        raw, how = v["hbm_bytes_raw"], "per launch"
-                        if is_g1 and bc.get("msm_a_b1_c_in_one_launch"):
-                            # that run launched the kernel twice per proof — once over the three tables of MSM A, B1, C, once for
-                            # MSM H — so the mean per LAUNCH is two MSMs' worth: per MSM (the unit of algorithmic_bytes) = x 2 / 4
-                            raw, how = int(raw * 2 / 4), "per G1 MSM (mean per launch x 2 launches / 4 MSMs: A, B1, C share one launch)"
-                        return raw, "replayed from %s (separate rocprofv3 --pmc passes; raw FETCH_SIZE + WRITE_SIZE %s)" % (os.path.relpath(path, ROOT), how)
-        except (OSError, ValueError, KeyError):
-            continue
-    return None, "no counter pass committed for this configuration"
 
 
 def multi_gpu_first_contact(args, dist, torch, dev, xdev, rank, world, share):
@@ -629,42 +668,6 @@ def multi_gpu_first_contact(args, dist, torch, dev, xdev, rank, world, share):
     return info
 
 
-def issue_bound_from_profiles(config, world, cus, clock, ms_per_step):
-    """The path's OWN roofline: it is bound by VALU issue, not by HBM.  One wave-level VALU instruction
-    of this path occupies its SIMD for ~4 cycles (v_mad_i64_i32 / 64-bit integer rate, profiles/r01_ubench_valu.txt), so
-        bound_ms = instructions per proof x 4 cycles / (SIMDs x shader clock).
-    Instructions per proof are NOT measured by this run (SQ_INSTS_VALU needs rocprofv3 --pmc around the process): like
-    `traffic` they are REPLAYED from the committed counter pass of this exact configuration
-    (profiles/*_valu_instruction_budget.json, written by tools/profile_bench.sh); the clock is sampled live while the
-    headline's timed region runs (rapidsnark_old_amd.telemetry)."""
-    import glob
-    keys = ("log2n", "parallelism", "window_bits", "precomputed_window_tables")
-    instr = src = per_kernel = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_instruction_budget.json")), key=profile_order, reverse=True):
-        try:
-            d = json.load(open(path))
-            bc = d.get("bench_config", {})
-            if all(bc.get(kk) == config.get(kk) for kk in keys) and bc.get("shape", "dense") == config.get("shape") and d.get("n_gpus") == world:
-                instr, per_kernel = d["valu_instructions_per_proof"], d.get("kernels")
-                src = "replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU pass of this command)" % os.path.relpath(path, ROOT)
-                break
-        except (OSError, ValueError, KeyError):
-            continue
-    simds = cus * 4
-    ghz = clock.get("clock_ghz")
-    out = {"valu_instructions_per_proof": instr, "instructions_source": src or "no SQ_INSTS_VALU pass committed for this configuration",
-           "cycles_per_instruction": 4.0, "simds": simds, "clock_ghz": ghz, "power_w": clock.get("power_w"), "clock_source": clock.get("source"),
-           "clock_samples": clock.get("samples"), "bound_ms": None, "achieved_frac": None,
-           "note": "bound_ms = valu_instructions_per_proof x cycles_per_instruction / (simds x clock_ghz); achieved_frac = bound_ms / ms_per_step "
-                   "(1.0 = every SIMD issues a VALU instruction of this path every 4 cycles for the whole period)"}
-    if instr and ghz:
-        out["bound_ms"] = round(instr * 4.0 / (simds * ghz * 1e9) * 1e3, 3)
-        out["achieved_frac"] = round(out["bound_ms"] / ms_per_step, 4)
-    if per_kernel:
-        out["largest_kernels"] = per_kernel
-    return out
-
-
 _LEGS = []
 
 
@@ -677,30 +680,8 @@ def leg_marker(zk, torch, name):
         return
     torch.cuda.synchronize()
     _LEGS.append(name)
-    n = 256 * (16 + len(_LEGS))
-    a = np.zeros(32 * n, dtype=np.uint8)
-    zk.fr_mul_vec(a, a)
-    torch.cuda.synchronize()
+    marker(zk, torch, 16 + len(_LEGS))
     sys.stderr.write("[bench] leg marker %d (grid of %d workgroups): %s\n" % (len(_LEGS), 16 + len(_LEGS), name))
-
-
-def batch_abc_default(witness_entries_per_prover, world):
-    """Mirror of the library's rule (csrc/prover.hip, zk_prover_create): MSM A, B1 and C as one set of launches unless the
-    prover is unsharded and holds 2^20 .. 2^22 - 1 witness entries; ZKHIP_BATCH_ABC overrides."""
-    e = os.environ.get("ZKHIP_BATCH_ABC")
-    if e is not None:
-        return e != "0"
-    return not (world == 1 and (1 << 20) <= witness_entries_per_prover < (1 << 22))
-
-
-def plan_window_bits(n, world, precomp):
-    """Mirror of make_msm_plan (csrc/msm.hip)."""
-    per = (n + world - 1) // world
-    lg = per.bit_length() - 1
-    if precomp:
-        c = 19 if lg == 20 else max(2, lg - 2)
-        return min(20, c)
-    return max(2, min(16, lg - 6))
 
 
 from rapidsnark_old_amd.views import view_from_workload, ProverFromView, MultiProverFromView      # noqa: E402,F401  (the wrappers live in the package)
@@ -719,66 +700,101 @@ def effective_cores():
 
 
 def cpu_baseline(wl, k, synth, prover, w0, w0_dev, budget_s):
-    """The ONLY place bench.py touches oracle/: the C restatement of rapidsnark's CPU algorithm
-    timed on this box's host cores, on a bounded sample of the same workload, and used as the
-    bit-exact checker of the GPU proof for the same (witness, r, s).  Timing: one warm-up proof
-    (a smaller member of the family: threads, page tables and caches are up afterwards), then as
-    many full proofs as the budget holds (at least one, at most five), median reported."""
+    """The ONLY place bench.py touches oracle/: the C restatement of rapidsnark's CPU algorithm (oracle/c/zk_oracle.c; OpenMP at
+    the reference's own parallel-for sites) timed on this box's host cores on the SAME workload and witness as the GPU, and used
+    as the bit-exact checker of the GPU proof for the same (witness, r, s).  Two builds of its field product are timed: `adx`
+    (mulx + adcx/adox carry chains: the instruction mix of the reference's ffiasm assembly, README.md:67-69) — the `value` when
+    the CPU has BMI2 + ADX — and `generic` (portable C over unsigned __int128).  One small warm-up proof, then as many full
+    proofs as the budget holds (median); when a full proof does not fit, the largest member of the family that does, scaled."""
     cores = effective_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)          # before libgomp is loaded: no oversubscription
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     from oracle import c_oracle as co
-    try:
-        co.build(march="native", out="_build/libzkoracle_native.so")
-        lib_path = os.path.join(ROOT, "oracle", "_build", "libzkoracle_native.so")
-        co.load(lib_path)
-        co._LIB = co.load(lib_path)
-    except Exception:
-        co.load()
-    co.set_num_threads(cores)
-    cores = co.num_threads()                             # threads actually used (= the CPU quota of this box)
-    # warm-up + probe at 2^16 to size the sample
-    kp = min(k, 16)
-    wlp = co.synth_workload(kp)
-    wp = synth.make_witness(kp)
-    co.prove(co.ZkeyView(wlp), wp, 1, 2)
-    t = time.perf_counter()
-    co.prove(co.ZkeyView(wlp), wp, 1, 2)
-    t_probe = time.perf_counter() - t
-    est_full = t_probe * (1 << (k - kp)) * 1.15
+    odir = os.path.join(ROOT, "oracle", "_build")
+    libs = []                                            # (variant, library), fastest first
+    for variant, adx in (("adx", True), ("generic", False)):
+        if adx and not co.cpu_has_adx():
+            continue
+        try:
+            name = "libzkoracle_native%s.so" % ("_adx" if adx else "")
+            co.build(march="native", out="_build/" + name, adx=adx)
+            libs.append((variant, co.load(os.path.join(odir, name))))
+        except Exception:           # noqa: BLE001  (no compiler on the box: the prebuilt portable library)
+            continue
+    if not libs:
+        libs = [("generic", co.load())]
     r, s = 0x1234567, 0x7654321
-    note = ("C restatement of rapidsnark's CPU algorithm (oracle/c/zk_oracle.c), gcc -O3 -march=native -fopenmp; "
-            "NOT ffiasm: hand-written ADX assembly may be 1.3-2x faster.  Parity unpinned at the reference boundary: the "
-            "reference ships no vectors and cannot be built in this image (DESIGN.md section 2), so 'bit-exact' below means "
-            "against this restatement, itself pinned by the trapdoor check and third-party vectors only")
-    if est_full <= budget_s * 1.5:
-        view = co.ZkeyView(wl)
-        times, proof_cpu = [], None
-        while len(times) < 5 and (not times or sum(times) + max(times) <= budget_s):      # as many as the budget holds
-            t = time.perf_counter()
-            proof_cpu = co.prove(view, w0, r, s)
-            times.append(time.perf_counter() - t)
-        runs = len(times)
-        dt = sorted(times)[len(times) // 2]
-        proof_gpu = prover.prove_host(w0, r, s)                  # the GPU proof through the reference's own entry point (host witness)
-        return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
-                "sample": "%d full proof(s) of the same 2^%d workload and witness after a 2^%d warm-up; median %.2f s (all: %s)" % (runs, k, kp, dt, ", ".join("%.2f" % x for x in times)),
-                "note": note, "gpu_proof_bit_exact_vs_cpu": proof_cpu == proof_gpu}
-    # too slow for the budget: largest size that fits, scaled linearly in n
-    ks = kp
-    while ks < k and t_probe * (1 << (ks + 1 - kp)) * 1.15 <= budget_s / 3:
-        ks += 1
-    wls = co.synth_workload(ks) if ks != kp else wlp
-    ws = synth.make_witness(ks)
-    times = []
-    for _ in range(3):
+    kp = min(k, 16)
+    res = {}
+    proof_gpu = prover.prove_host(w0, r, s)              # the GPU proof through the reference's own entry point (host witness)
+    left = budget_s
+    for vi, (variant, lib) in enumerate(libs):
+        co._LIB = lib
+        co.set_num_threads(cores)
+        cores = co.num_threads()                         # threads actually used (= the CPU quota of this box)
+        wlp = co.synth_workload(kp)
+        wp = synth.make_witness(kp)
+        co.prove(co.ZkeyView(wlp), wp, 1, 2)             # warm-up: threads, page tables, caches
         t = time.perf_counter()
-        co.prove(co.ZkeyView(wls), ws, r, s)
-        times.append(time.perf_counter() - t)
-    dt = sorted(times)[1]
-    return {"value": round(1.0 / (dt * (1 << (k - ks))), 5), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "median of 3 proofs of the 2^%d member of the same synthetic family (%.2f s), scaled x%d to 2^%d (linear in n)" % (ks, dt, 1 << (k - ks), k),
-            "note": note}
+        co.prove(co.ZkeyView(wlp), wp, 1, 2)
+        t_probe = time.perf_counter() - t
+        est = t_probe * (1 << (k - kp)) * 0.8            # (a 2^16 proof is less efficient per constraint than a 2^22 one)
+        # the fastest variant gets up to 60 % of the budget (as many full proofs as fit, at most three); the other one what is left
+        share = left * 0.6 if (vi == 0 and len(libs) > 1) else left
+        if est <= share:
+            view, times, proof_cpu = co.ZkeyView(wl), [], None
+            while len(times) < 3 and (not times or sum(times) + max(times) <= share):
+                t = time.perf_counter()
+                proof_cpu = co.prove(view, w0, r, s)
+                times.append(time.perf_counter() - t)
+            left -= sum(times)
+            dt = sorted(times)[len(times) // 2]
+            res[variant] = {"s_per_proof": round(dt, 3), "proofs": len(times), "bit_exact": proof_cpu == proof_gpu,
+                            "sample": "%d full proof(s) of the same 2^%d workload and witness after a 2^%d warm-up; median %.2f s" % (len(times), k, kp, dt)}
+        elif vi == 0:                                    # too slow for the budget: the largest size that fits, scaled linearly in n
+            ks = kp
+            while ks < k and t_probe * (1 << (ks + 1 - kp)) * 1.15 <= share / 3:
+                ks += 1
+            wls = co.synth_workload(ks) if ks != kp else wlp
+            ws = synth.make_witness(ks)
+            times = []
+            for _ in range(3):
+                t = time.perf_counter()
+                co.prove(co.ZkeyView(wls), ws, r, s)
+                times.append(time.perf_counter() - t)
+            left -= sum(times)
+            dt = sorted(times)[1] * (1 << (k - ks))
+            res[variant] = {"s_per_proof": round(dt, 3), "proofs": 3, "bit_exact": None,
+                            "sample": "median of 3 proofs of the 2^%d member of the same family, scaled x%d to 2^%d (linear in n)" % (ks, 1 << (k - ks), k)}
+    best = libs[0][0]
+    out = {"value": round(1.0 / res[best]["s_per_proof"], 5), "unit": "proofs/s", "cores": cores, "kind": "port", "variant": best,
+           "sample": res[best]["sample"], "s_per_proof": res[best]["s_per_proof"], "gpu_proof_bit_exact_vs_cpu": res[best]["bit_exact"]}
+    if "generic" in res and best != "generic":
+        out["generic_s_per_proof"], out["generic_bit_exact"] = res["generic"]["s_per_proof"], res["generic"]["bit_exact"]
+    out["note"] = "oracle/c/zk_oracle.c, gcc -O3 -march=native -fopenmp; parity unpinned at the reference boundary (DESIGN.md section 2)"
+    return out
+
+
+def server_leg():
+    """BASELINE configs[4] on one GPU, proxy key: tools/server_bench.py drives the proverServer executable over REST (keep-alive
+    clients, /witness) on a Semaphore-class zkgen key and checks every proof; -> the also_server object, or why it did not run."""
+    import subprocess
+    exe = os.path.join(ROOT, "rapidsnark-old_amd", "proverServer")
+    tool = os.path.join(ROOT, "tools", "server_bench.py")
+    if not (os.path.exists(exe) and os.path.exists(tool)):
+        return {"value": None, "error": "proverServer / tools/server_bench.py not built"}
+    try:
+        r = subprocess.run([sys.executable, tool, "15", "512", "0", "witness", "semaphore"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           timeout=150, text=True, cwd=ROOT)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"value": None, "error": "server_bench rc %d" % r.returncode}
+        d = json.loads(line[-1])
+        return {"value": d["proofs_per_s"], "unit": "proofs/s", "n_gpus": 1, "log2n": d["log2n"], "requests": d["requests"], "route": d["route"],
+                "succeeded": d["succeeded"], "proofs_equal_to_the_trapdoor_prediction": d["proofs_equal_to_the_trapdoor_prediction"],
+                "key": d.get("key", "zkgen proxy key (no Semaphore / iden3-auth zkey exists in the image)"), "ms_per_proof": d["ms_per_proof"]}
+    except Exception as exc:           # noqa: BLE001
+        return {"value": None, "error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
 
 
 if __name__ == "__main__":

@@ -140,12 +140,33 @@ void zk_host_free(void *ptr);
 int zk_prove_collect(zk_prover *p, zk_proof *out);
 /* Per-proof workspace is allocated the first time a slot / lane is used (the one-shot CLI never needs more than one).  A
  * server that will keep `in_flight` proofs in flight calls this once after create: every proof slot and lane such a
- * pipeline walks (all ZK_MAX_IN_FLIGHT of them when in_flight >= 2, slot 0 for 1) is allocated NOW — with
+ * pipeline walks (in_flight + 1 slots of the ring, at most ZK_MAX_IN_FLIGHT; slot 0 alone for 1) is allocated NOW — with
  * host_witnesses != 0 including the per-slot HBM witness buffer and its pinned staging copy — so that running out of
  * device memory is a start-up error the caller can react to (tables as in the zkey instead of the window-precomputed
  * ones) and never a failed proof later.  Replaces nothing in the reference (its workspace is `new FrElement[]` per proof,
  * src/groth16.cpp:52-60). */
 int zk_prover_reserve(zk_prover *p, uint32_t in_flight, uint32_t host_witnesses);
+/* What zk_prover_create decided for this key on this device — the launch plan a benchmark, a server or a log line reports
+ * (and sizes its pipeline by) instead of re-deriving the library's rules.  Set plan->size = sizeof(zk_prover_plan) before
+ * the call (fields may be appended in later versions; only `size` bytes are written).  Replaces nothing in the
+ * reference: its plan is fixed in code (one proof at a time, src/fullprover.cpp:96-97; window chosen inside ffiasm). */
+typedef struct zk_prover_plan {
+    uint32_t size;
+    uint32_t window_bits_h, windows_h;     /* Pippenger window c of MSM H; digits = point additions per point */
+    uint32_t window_bits_w, windows_w;     /* the same for the witness MSMs A, B1, B2, C (differs with ZK_FLAG_SPARSE_WITNESS) */
+    uint32_t precomputed_tables;           /* ZK_FLAG_PRECOMP in effect */
+    uint32_t msm_a_b1_c_one_launch;        /* MSM A, B1, C as ONE set of launches over three tables (blockIdx.y) */
+    uint32_t lanes;                        /* independent sets of compute streams: proof k runs on lane k % lanes */
+    uint32_t follow_up_streams;            /* high-priority streams for merges / reductions (sharded provers) */
+    uint32_t max_in_flight;                /* ZK_MAX_IN_FLIGHT */
+    uint32_t depth_host_witness;           /* proofs in flight that saturate this prover: witnesses in host memory ... */
+    uint32_t depth_resident_witness;       /* ... and already resident in HBM (no upload to hide) */
+    uint32_t batch;                        /* opts.batch in effect (1 = single-witness submissions) */
+    uint32_t shard_index, shard_count, chain_partitioned;
+    uint64_t device_bytes_in_use;          /* HBM in use on the prover's device right now (all processes), from the runtime */
+    uint64_t device_bytes_total;
+} zk_prover_plan;
+int zk_prover_info(zk_prover *p, zk_prover_plan *plan);
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);
 /* Batched proving (a prover created with opts.batch = B >= 2): `count` (1..B) witnesses of the circuit, given as
  * `count` host pointers, are proved by ONE submission — one digit sort with a bucket set per witness, one set of

@@ -103,7 +103,50 @@ static inline void f_neg(const field_t *F, fe *r, const fe *a) {
     fe z = {{0, 0, 0, 0}};
     f_sub(F, r, &z, a);
 }
-/* Montgomery product a*b*R^-1 mod p  (E.fr.mul / E.f1.mul) */
+/* Montgomery product a*b*R^-1 mod p  (E.fr.mul / E.f1.mul).  Two builds of the SAME function (identical results, checked
+ * against each other by tests/test_oracle_c.py):
+ *   default          portable C: CIOS over unsigned __int128 (what gcc makes of it: mulx + one adc chain)
+ *   -DZK_ORACLE_ADX  x86-64 with BMI2 + ADX: mulx with the two independent carry chains of adcx / adox — the instruction
+ *                    mix of the "intel assembly with ADX extensions" the reference's README.md:67-69 names for its field
+ *                    arithmetic (ffiasm generates it with nasm; ffiasm itself is absent from the checkout, so this is the
+ *                    published technique restated, not its code).  BN254's primes leave the top bit of the top limb clear,
+ *                    so the running value never needs a sixth limb ("no-carry" CIOS). */
+#if defined(ZK_ORACLE_ADX) && defined(__x86_64__) && defined(__ADX__) && defined(__BMI2__)
+#define ZK_ORACLE_VARIANT "adx"
+/* one CIOS round: t += a * b[i];  m = t0 * ninv;  t += m * p;  t >>= 64.  T0..T3 hold t on entry (its fifth limb is zero),
+ * T1, T2, T3, T4 on exit (T0 is scratch).  rdx, rax, r8, r9 are scratch. */
+#define ZK_ADX_ROUND(I, T0, T1, T2, T3, T4)                                                                         \
+    "movq " #I "*8(%[b]), %%rdx\n\t"                                                                                \
+    "xorl %%eax, %%eax\n\t"                                                                                         \
+    "mulxq 0(%[a]), %%rax, %%r8\n\t"   "adcxq %%rax, %[" #T0 "]\n\t"                                                \
+    "mulxq 8(%[a]), %%rax, %%r9\n\t"   "adcxq %%rax, %[" #T1 "]\n\t"  "adoxq %%r8, %[" #T1 "]\n\t"                   \
+    "mulxq 16(%[a]), %%rax, %%r8\n\t"  "adcxq %%rax, %[" #T2 "]\n\t"  "adoxq %%r9, %[" #T2 "]\n\t"                   \
+    "mulxq 24(%[a]), %%rax, %[" #T4 "]\n\t" "adcxq %%rax, %[" #T3 "]\n\t"  "adoxq %%r8, %[" #T3 "]\n\t"              \
+    "movl $0, %%eax\n\t"               "adcxq %%rax, %[" #T4 "]\n\t"  "adoxq %%rax, %[" #T4 "]\n\t"                  \
+    "movq %[" #T0 "], %%rdx\n\t"       "imulq 96(%[F]), %%rdx\n\t"                                                  \
+    "xorl %%eax, %%eax\n\t"                                                                                         \
+    "mulxq 0(%[F]), %%rax, %%r8\n\t"   "adcxq %[" #T0 "], %%rax\n\t"                                                \
+    "mulxq 8(%[F]), %%rax, %%r9\n\t"   "adcxq %%rax, %[" #T1 "]\n\t"  "adoxq %%r8, %[" #T1 "]\n\t"                   \
+    "mulxq 16(%[F]), %%rax, %%r8\n\t"  "adcxq %%rax, %[" #T2 "]\n\t"  "adoxq %%r9, %[" #T2 "]\n\t"                   \
+    "mulxq 24(%[F]), %%rax, %%r9\n\t"  "adcxq %%rax, %[" #T3 "]\n\t"  "adoxq %%r8, %[" #T3 "]\n\t"                   \
+    "movl $0, %%eax\n\t"               "adcxq %%r9, %[" #T4 "]\n\t"   "adoxq %%rax, %[" #T4 "]\n\t"                  \
+    "movl $0, %k[" #T0 "]\n\t"
+static inline void f_mul(const field_t *F, fe *r, const fe *a, const fe *b) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    __asm__(ZK_ADX_ROUND(0, t0, t1, t2, t3, t4)
+            ZK_ADX_ROUND(1, t1, t2, t3, t4, t0)
+            ZK_ADX_ROUND(2, t2, t3, t4, t0, t1)
+            ZK_ADX_ROUND(3, t3, t4, t0, t1, t2)
+            : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [t4] "+&r"(t4)
+            : [a] "r"(a->v), [b] "r"(b->v), [F] "r"(F), "m"(*a), "m"(*b), "m"(*F)
+            : "rax", "rdx", "r8", "r9", "cc");
+    /* four rounds rotate the names by four: the value is (t4, t0, t1, t2) */
+    fe o = {{t4, t0, t1, t2}};
+    if (geq(o.v, F->p)) sub_p(o.v, F->p);
+    *r = o;
+}
+#else
+#define ZK_ORACLE_VARIANT "generic"
 static inline void f_mul(const field_t *F, fe *r, const fe *a, const fe *b) {
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
@@ -133,6 +176,7 @@ static inline void f_mul(const field_t *F, fe *r, const fe *a, const fe *b) {
     if (t[4] || geq(o.v, F->p)) sub_p(o.v, F->p);
     *r = o;
 }
+#endif
 static inline void f_sqr(const field_t *F, fe *r, const fe *a) { f_mul(F, r, a, a); }
 static inline void f_one(const field_t *F, fe *r) { memcpy(r->v, F->r1, 32); }
 static inline void f_to_mont(const field_t *F, fe *r, const fe *a) {
@@ -165,16 +209,27 @@ static inline int f2_eq(const fe2 *x, const fe2 *y) { return fe_eq(&x->a, &y->a)
 static inline void f2_add(fe2 *r, const fe2 *x, const fe2 *y) { f_add(&FQ, &r->a, &x->a, &y->a); f_add(&FQ, &r->b, &x->b, &y->b); }
 static inline void f2_sub(fe2 *r, const fe2 *x, const fe2 *y) { f_sub(&FQ, &r->a, &x->a, &y->a); f_sub(&FQ, &r->b, &x->b, &y->b); }
 static inline void f2_neg(fe2 *r, const fe2 *x) { f_neg(&FQ, &r->a, &x->a); f_neg(&FQ, &r->b, &x->b); }
+/* (a + b u)(c + d u), u^2 = -1: three base-field products (Karatsuba), as the reference's F2Field does (ffiasm f2field:
+ * aA = a*c, bB = b*d, (a + b)(c + d) - aA - bB); the square is the "complex" one, two products */
 static inline void f2_mul(fe2 *r, const fe2 *x, const fe2 *y) {
-    fe aa, bb, ab, ba;
+    fe aa, bb, s, t, m;
     f_mul(&FQ, &aa, &x->a, &y->a);
     f_mul(&FQ, &bb, &x->b, &y->b);
-    f_mul(&FQ, &ab, &x->a, &y->b);
-    f_mul(&FQ, &ba, &x->b, &y->a);
+    f_add(&FQ, &s, &x->a, &x->b);
+    f_add(&FQ, &t, &y->a, &y->b);
+    f_mul(&FQ, &m, &s, &t);
+    f_sub(&FQ, &m, &m, &aa);
+    f_sub(&FQ, &r->b, &m, &bb);
     f_sub(&FQ, &r->a, &aa, &bb);
-    f_add(&FQ, &r->b, &ab, &ba);
 }
-static inline void f2_sqr(fe2 *r, const fe2 *x) { fe2 t = *x; f2_mul(r, &t, &t); }
+static inline void f2_sqr(fe2 *r, const fe2 *x) {
+    fe s, d, ab;
+    f_add(&FQ, &s, &x->a, &x->b);
+    f_sub(&FQ, &d, &x->a, &x->b);
+    f_mul(&FQ, &ab, &x->a, &x->b);
+    f_mul(&FQ, &r->a, &s, &d);
+    f_add(&FQ, &r->b, &ab, &ab);
+}
 static inline void f2_one(fe2 *r) { f_one(&FQ, &r->a); memset(&r->b, 0, 32); }
 static void f2_inv(fe2 *r, const fe2 *x) {
     fe t0, t1, d;
@@ -581,6 +636,7 @@ static void final_assembly(const oracle_zkey_view *z, const oracle_msm_sums *m, 
 
 /* ------------------------------------------------------------------ exported C API (ctypes) */
 int oracle_num_threads(void) { return omp_get_max_threads(); }
+const char *oracle_variant(void) { return ZK_ORACLE_VARIANT; }      /* "adx" or "generic": which build of f_mul this library holds */
 void oracle_set_num_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

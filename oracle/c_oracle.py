@@ -23,11 +23,22 @@ class oracle_zkey_view(C.Structure):
                 ("pointsC", C.c_void_p), ("pointsH", C.c_void_p)]
 
 
-def build(march=None, out=None):
-    """Compile the C restatement (gcc, OpenMP).  march='native' on the box that times it."""
+def cpu_has_adx():
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return " adx" in flags and " bmi2" in flags
+
+
+def build(march=None, out=None, adx=False):
+    """Compile the C restatement (gcc, OpenMP).  march='native' on the box that times it; adx=True: the field product
+    with mulx / adcx / adox (-DZK_ORACLE_ADX; the CPU must have BMI2 + ADX)."""
     args = ["make", "-s", "-C", _HERE]
     if march:
         args.append("MARCH=%s" % march)
+    if adx:
+        args.append("EXTRA=-DZK_ORACLE_ADX")
     if out:
         args.append("OUT=%s" % out)
         if os.path.exists(os.path.join(_HERE, out)):
@@ -45,6 +56,8 @@ def load(path=None):
     lib = C.CDLL(p)
     v = C.c_void_p
     lib.oracle_num_threads.restype = C.c_int
+    if hasattr(lib, "oracle_variant"):
+        lib.oracle_variant.restype = C.c_char_p
     lib.oracle_set_num_threads.argtypes = [C.c_int]
     lib.oracle_set_num_threads.restype = None
     for n in ("oracle_fr_mul_vec", "oracle_fq_mul_vec"):

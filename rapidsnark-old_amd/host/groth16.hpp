@@ -170,30 +170,44 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     // NOW (zk_prover_reserve) — slots and lanes otherwise appear when a depth is first reached, and a GPU whose tables
     // nearly fill its memory would create successfully and fail proofs later
     uint32_t reserved = 0;
+    auto oom = [] { return strstr(zk_last_error(), "out of memory") != nullptr; };
+    // create, then reserve the pipeline: the depth asked for, else (out of memory) two in flight on the SAME prover before
+    // anything is given up — a shallower pipeline over window-precomputed tables (13 instead of 16 additions per point) is
+    // faster than a deep one over the tables as in the zkey (2^22: 36.8 ms at two in flight against 38.4 at six)
     auto create = [&](uint32_t reserve) {
         int rc = zk_prover_create(&h, &v, &o);
-        if (rc == 0 && reserve && (rc = zk_prover_reserve(h, reserve, 1)) != 0) {
-            zk_prover_destroy(h);
-            h = nullptr;
+        if (rc != 0 || !reserve) return rc;
+        rc = zk_prover_reserve(h, reserve, 1);
+        if (rc == 0) {
+            reserved = reserve;
+            return 0;
         }
-        if (rc == 0) reserved = reserve;
+        if (reserve > 2 && oom()) {
+            std::cerr << "the workspace of " << reserve << " proofs in flight does not fit the GPU's free memory: two in flight\n";
+            rc = zk_prover_reserve(h, 2, 1);
+            if (rc == 0) {
+                reserved = 2;
+                return 0;
+            }
+        }
+        zk_prover_destroy(h);
+        h = nullptr;
         return rc;
     };
-    auto oom = [] { return strstr(zk_last_error(), "out of memory") != nullptr; };
     int rc = create(reserveInFlight);
     // window-precomputed tables are 13 x the table memory (2^26 constraints: > 288 GB): where they were only the DEFAULT
-    // (proverServer) and they, or the proof workspace beside them, do not fit, the prover is created with the tables as they
-    // are in the zkey instead of not at all
+    // (proverServer) and they, or the workspace of even two proofs beside them, do not fit, the prover is created with the
+    // tables as they are in the zkey instead of not at all
     if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !pc && oom()) {
         std::cerr << "window-precomputed tables do not fit the GPU's free memory: using the tables as in the zkey\n";
         o.flags &= ~(uint32_t)ZK_FLAG_PRECOMP;
         o.batch = 0;
         rc = create(reserveInFlight);
     }
-    // ... and where even then the workspace of a whole pipeline does not fit: one proof at a time (the caller reads the depth
+    // ... and where even then the workspace of a pipeline does not fit: one proof at a time (the caller reads the depth
     // it may use from reservedInFlight())
     if (rc != 0 && reserveInFlight > 1 && oom()) {
-        std::cerr << "the workspace of " << reserveInFlight << " proofs in flight does not fit the GPU's free memory: one proof at a time\n";
+        std::cerr << "the workspace of two proofs in flight does not fit the GPU's free memory: one proof at a time\n";
         rc = create(1);
     }
     if (rc != 0) throw std::runtime_error(zk_last_error());

@@ -42,6 +42,22 @@ class zk_msm_sums(C.Structure):
                 ("pi_b", C.c_uint8 * 128), ("pi_c", C.c_uint8 * 64)]
 
 
+class zk_prover_plan(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("window_bits_h", C.c_uint32), ("windows_h", C.c_uint32), ("window_bits_w", C.c_uint32),
+                ("windows_w", C.c_uint32), ("precomputed_tables", C.c_uint32), ("msm_a_b1_c_one_launch", C.c_uint32), ("lanes", C.c_uint32),
+                ("follow_up_streams", C.c_uint32), ("max_in_flight", C.c_uint32), ("depth_host_witness", C.c_uint32),
+                ("depth_resident_witness", C.c_uint32), ("batch", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("chain_partitioned", C.c_uint32), ("device_bytes_in_use", C.c_uint64), ("device_bytes_total", C.c_uint64)]
+
+
+def prover_info(lib, handle):
+    """zk_prover_info -> dict: the launch plan zk_prover_create chose (window bits, A|B1|C in one launch, lanes, depths)."""
+    plan = zk_prover_plan()
+    plan.size = C.sizeof(zk_prover_plan)
+    check(lib.zk_prover_info(handle, C.byref(plan)))
+    return {name: int(getattr(plan, name)) for name, _ in zk_prover_plan._fields_ if name != "size"}
+
+
 ZK_FLAG_TIMINGS = 1
 ZK_FLAG_PRECOMP = 2
 ZK_FLAG_PARTITIONED_CHAIN = 4
@@ -51,7 +67,7 @@ ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "ms
 
 # every symbol include/zkhip.h declares (tests check the library exports all of them)
 EXPORTS = ["zk_last_error", "zk_device_count", "zk_prover_create", "zk_prover_destroy", "zk_prove", "zk_prove_dev",
-           "zk_prove_dev_submit", "zk_prove_submit", "zk_prove_batch_submit", "zk_prove_batch_collect", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prover_reserve", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
+           "zk_prove_dev_submit", "zk_prove_submit", "zk_prove_batch_submit", "zk_prove_batch_collect", "zk_host_alloc", "zk_host_free", "zk_prove_collect", "zk_prover_reserve", "zk_prover_info", "zk_prove_msm_collect", "zk_prove_msm_dev", "zk_prove_msm", "zk_prove_finish", "zk_prover_timings", "zk_fr_mul_vec",
            "zk_fq_mul_vec", "zk_fr_coef_accumulate", "zk_fr_ntt", "zk_fr_abc_to_h", "zk_msm_g1", "zk_msm_g2", "zk_proof_to_json",
            "zk_public_to_json", "zk_synth_chain_g1", "zk_synth_chain_g2", "zk_fixed_base_g1", "zk_fixed_base_g2", "zk_g1_mul", "zk_g2_mul", "zk_assemble",
            "zk_multi_prover_create", "zk_multi_prover_destroy", "zk_multi_prove", "zk_multi_prove_submit", "zk_multi_prove_collect",
@@ -100,6 +116,8 @@ def load_library():
     lib.zk_prover_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     if hasattr(lib, "zk_prover_reserve"):      # (ZKHIP_LIB may name an older build of the library: same-box A/B runs)
         lib.zk_prover_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    if hasattr(lib, "zk_prover_info"):
+        lib.zk_prover_info.argtypes = [C.c_void_p, C.POINTER(zk_prover_plan)]
     lib.zk_multi_prover_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(zk_zkey_view), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(zk_opts)]
     lib.zk_multi_prover_destroy.argtypes = [C.c_void_p]
     lib.zk_multi_prover_destroy.restype = None

@@ -175,6 +175,10 @@ class Prover:
         start-up check: out of device memory is raised here, not by a proof later)."""
         L.check(self._lib.zk_prover_reserve(self._h, in_flight, 1 if host_witnesses else 0))
 
+    def info(self):
+        """zk_prover_info: the launch plan chosen at create, as a dict."""
+        return L.prover_info(self._lib, self._h)
+
     def timings(self):
         ms = (C.c_double * len(L.ZK_T_NAMES))()
         L.check(self._lib.zk_prover_timings(self._h, ms, len(L.ZK_T_NAMES)))

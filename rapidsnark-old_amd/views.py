@@ -138,6 +138,10 @@ class ProverFromView:
         """zk_prover_reserve: every slot / lane a pipeline of `in_flight` proofs walks, allocated now (raises on out of memory)."""
         self.L.check(self.lib.zk_prover_reserve(self.h, in_flight, 1 if host_witnesses else 0))
 
+    def info(self):
+        """zk_prover_info: the launch plan chosen at create, as a dict."""
+        return self.L.prover_info(self.lib, self.h)
+
     def timings(self):
         ms = (self.C.c_double * len(self.L.ZK_T_NAMES))()
         self.L.check(self.lib.zk_prover_timings(self.h, ms, len(self.L.ZK_T_NAMES)))

@@ -100,3 +100,41 @@ def test_eip196_public_vectors_c():
     p, q, s = EIP196_ADD
     one = bn.int_to_le32(1)
     assert co.msm_g1(bn.g1_to_bytes(p) + bn.g1_to_bytes(q), one + one) == bn.g1_to_bytes(s)
+
+
+@pytest.mark.skipif(not co.cpu_has_adx(), reason="the CPU of this box has no BMI2 + ADX")
+def test_adx_build_of_the_field_product_equals_the_portable_one():
+    """-DZK_ORACLE_ADX (mulx + adcx/adox: the cpu_baseline's fast variant) against the portable C build: the field KATs, the
+    edge operands of a Montgomery product, and whole proofs of the golden circuits, byte for byte."""
+    import os
+    import numpy as np
+    here = os.path.dirname(co.__file__)
+    co.build(march="native", out="_build/libzkoracle_test_adx.so", adx=True)
+    adx = co.load(os.path.join(here, "_build", "libzkoracle_test_adx.so"))
+    assert adx.oracle_variant() == b"adx" and co.load().oracle_variant() == b"generic"
+    import ctypes as C
+    rnd = random.Random(5)
+    for field, mod in (("fr", bn.R_MOD), ("fq", bn.Q_MOD)):
+        edge = [0, 1, 2, mod - 1, mod - 2, (1 << 253) + 12345, mod // 2, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, (1 << 192) + 7]
+        vals = edge + [rnd.randrange(mod) for _ in range(500)]
+        a = pack(vals + vals[::-1]) 
+        b = pack(vals[::-1] + [vals[(3 * i) % len(vals)] for i in range(len(vals))])
+        want = (co.fr_mul_vec if field == "fr" else co.fq_mul_vec)(a, b)
+        aa, bb = np.frombuffer(a, dtype=np.uint8), np.frombuffer(b, dtype=np.uint8)
+        out = np.zeros(aa.size, dtype=np.uint8)
+        getattr(adx, "oracle_%s_mul_vec" % field)(C.c_void_p(out.ctypes.data), C.c_void_p(aa.ctypes.data), C.c_void_p(bb.ctypes.data), aa.size // 32)
+        assert out.tobytes() == want
+    saved = co._LIB
+    try:
+        for name in CIRCUITS:
+            meta = golden_json(name, "meta.json")
+            from oracle import groth16_ref as g
+            wt = g.read_wtns(golden_bytes(name, "witness.wtns"))
+            vals = pack(wt["witness"])
+            co._LIB = saved
+            ref = co.prove(co.ZkeyView(golden_bytes(name, "circuit.zkey")), vals, int(meta["r"]), int(meta["s"]))
+            co._LIB = adx
+            got = co.prove(co.ZkeyView(golden_bytes(name, "circuit.zkey")), vals, int(meta["r"]), int(meta["s"]))
+            assert got == ref and got.hex() == meta["proof_bytes"]
+    finally:
+        co._LIB = saved

@@ -1,4 +1,4 @@
-// Random-row gather bandwidth on MI355X: rows of 64 B / 128 B from tables of 256 MB .. 7 GB.
+// Random-row gather bandwidth on MI355X: rows of 64 B / 128 B from tables of 256 MB .. 10 GB.
 // Index stream is read coalesced (4 B per row), rows are summed into a register (no stores).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/gather_probe tools/gather_probe.hip
 #include <hip/hip_runtime.h>
@@ -42,12 +42,14 @@ int main() {
     const uint64_t n = 54525952;     // 13 * 2^22 gathers, as one precomputed-table MSM at 2^22
     std::vector<uint32_t> h(n);
     uint32_t *d_idx; uint4 *d_sink; uint4 *d_table;
-    const uint64_t max_bytes = 7ull << 30;
+    const uint64_t max_bytes = 10ull << 30;
     CK(hipMalloc(&d_idx, n * 4)); CK(hipMalloc(&d_sink, 64)); CK(hipMalloc(&d_table, max_bytes));
     CK(hipMemset(d_table, 1, max_bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int row = 64; row <= 128; row *= 2) {
-        for (uint64_t mb : {256ull, 1024ull, 3584ull, 7168ull}) {
+        // 3584 MB ~ one window-precomputed G1 table at 2^22 (3.25 GiB), 6656 MB = the G2 table (6.5 GiB), 10240 MB ~ the three
+        // G1 tables the A|B1|C launch gathers from at once (9.75 GiB)
+        for (uint64_t mb : {256ull, 1024ull, 3584ull, 6656ull, 7168ull, 10240ull}) {
             uint64_t rows = (mb << 20) / row;
             uint64_t x = 88172645463325252ull;
             for (uint64_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (uint32_t)(x % rows); }
