@@ -198,11 +198,13 @@ static std::shared_ptr<const DeltaTables> delta_tables(const uint8_t vk_delta1[6
                 return hit;
             }
     }
-    auto t = std::make_shared<DeltaTables>();          // built outside the lock: two threads may build the same key once
+    auto t = std::make_shared<DeltaTables>();          // built outside the lock: the threads of a first batched submission may each build it once
     memcpy(t->key, key, 192);
     t->d1.build(load<G1A>(vk_delta1));
     t->d2.build(load<G2A>(vk_delta2));
     std::lock_guard<std::mutex> lk(m);
+    for (auto &e : lru)                                // ... but only ONE copy enters the cache: duplicates of a key evicted the tables of the server's other circuits
+        if (!memcmp(e->key, key, 192)) return e;
     lru.push_front(t);
     if (lru.size() > 16) lru.pop_back();
     return t;

@@ -1,4 +1,4 @@
-// Small persistent thread pool for the host tails of a batched submission (prover.hip) — in a header of its own so that
+// Small persistent thread pool for the host tails of a batched submission (prover_pipeline.hip) — in a header of its own so that
 // tools/tail_pool_test.cpp can hammer it without a GPU (tests/test_host_cpu.py).
 #pragma once
 #include <atomic>
@@ -17,6 +17,8 @@ namespace zk {
 // submission = 2.4 ms of tail for 1.6 ms of GPU work.  A few persistent threads shared by every prover of the process; the
 // calling thread takes its share, so a machine with no spare core still makes progress.
 struct TailPool {
+    // fn points at the CALLER's std::function: valid because for_each() returns only when done == count, i.e. after the last
+    // call of fn has returned — a job whose indices are all handed out is never entered again (work() leaves at next >= count).
     struct Job { const std::function<void(uint32_t)> *fn; std::atomic<uint32_t> next{0}, done{0}; uint32_t count = 0; };
     std::mutex m;
     std::condition_variable cv, fin;
@@ -40,9 +42,13 @@ struct TailPool {
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return !q.empty(); });
-                j = q.front();
-                if (j->next.load() >= j->count) { q.pop_front(); continue; }
+                // any job that still has indices to hand out — not just the front one: with several GPUs, each running its own
+                // collector, the batched tails of one submission used to queue behind another's last straggler
+                cv.wait(lk, [&] {
+                    for (auto &x : q)
+                        if (x->next.load() < x->count) { j = x; return true; }
+                    return false;
+                });
             }
             work(*j);
             std::lock_guard<std::mutex> lk(m);

@@ -308,19 +308,38 @@ bool FullProver::enqueueWitness(std::string wtnsImage, std::string circuit, uint
         if (incoming.size() + inWitness + readyJobs.size() >= queueCap) return false;
         inWitness++;
     }
-    JobPtr j = std::make_shared<Job>();
-    j->circuit = std::move(circuit);
+    // the reserved place is given back on EVERY way out of the parsing below — a bad_alloc beside a 128 MB body or any other
+    // exception that is not a std::exception used to leave it taken for good (the queue answered 503 forever after enough of them)
+    struct Place {
+        FullProver *fp;
+        bool held = true;
+        void release_locked() {
+            if (held) fp->inWitness--;
+            held = false;
+        }
+        ~Place() {
+            if (!held) return;
+            std::lock_guard<std::mutex> guard(fp->mtx);
+            fp->inWitness--;
+        }
+    } place{this};
+    JobPtr j;
     std::string error;
     try {        // nothing here needs the prover's lock
+        j = std::make_shared<Job>();
+        j->circuit = std::move(circuit);
         auto known = circuits.find(j->circuit);
         if (known == circuits.end()) throw std::runtime_error("unknown circuit: " + j->circuit);
         j->wtns = BinFileUtils::fromMemory(std::move(wtnsImage), "wtns", 2);
         adoptWitness(*j, known->second.header.get());
     } catch (std::exception &e) {
         error = e.what();
+    } catch (...) {
+        error = "witness could not be read";
     }
+    if (!j) throw std::runtime_error("out of memory for a witness job");        // (the place is released by ~Place; the HTTP layer answers 500)
     std::lock_guard<std::mutex> guard(mtx);
-    inWitness--;                                 // the reserved place becomes a ready job (or is given back)
+    place.release_locked();                      // the reserved place becomes a ready job (or is given back)
     j->id = id = nextId++;
     j->epoch = abortEpoch;
     remember(j);

@@ -5,7 +5,12 @@
 // Every socket is NON-BLOCKING and every connection carries its own parse state, so a worker never waits for one client:
 // a slow or large upload (bodies go up to 128 MB), a client trickling a byte every few seconds or a peer that does not
 // read its answer costs that connection's poll slot, nothing else — the cheap /status polls and accept() on the same
-// worker go on.  Deadlines: a request must be complete `kRequestDeadlineMs` after its first byte, an idle kept-alive
+// worker go on.  What a worker DOES wait for is the handler itself, which runs on the worker's thread: a /status poll takes
+// microseconds, a /witness body is parsed there (tens of milliseconds for a 128 MB image) and the worker's other connections
+// wait that long.  Memory is bounded per connection and per worker: a connection whose unsent answers exceed kMaxPendingOut is
+// neither read nor parsed until its peer has taken them (a client that pipelines requests and never reads costs 1 MB, not the
+// server's memory); a worker holds at most kMaxConns connections (the listening socket is left to the other workers and the
+// backlog beyond that) and buffers at most kMaxBigBodies bodies above 1 MB at a time (the next one is answered 503).  Deadlines: a request must be complete `kRequestDeadlineMs` after its first byte, an idle kept-alive
 // connection is dropped after `kIdleMs`, a refused request's unread body is drained for at most `kDrainMs` (closing a
 // socket with unread data sends a reset that can overtake the answer).  accept() failing with EMFILE & co. pauses
 // accepting on that worker for 100 ms instead of spinning on a listening socket that stays readable.
@@ -42,6 +47,9 @@ static const int64_t kRequestDeadlineMs = 120000;  // first byte of a request ->
 static const int64_t kIdleMs = 30000;              // kept-alive connection with nothing in flight
 static const int64_t kDrainMs = 1000;              // reading and dropping what a refused client still sends
 static const size_t kMaxHeader = 65536;
+static const size_t kMaxPendingOut = (size_t)1 << 20;   // unsent response bytes of one connection beyond which it is not read
+static const size_t kMaxConns = 1024;                    // connections one worker holds
+static const size_t kBigBody = (size_t)1 << 20, kMaxBigBodies = 4;   // bodies above kBigBody being received by one worker at a time
 
 inline int64_t now_ms() {
     return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -54,12 +62,13 @@ inline std::string lower(std::string s) {
 struct Conn {
     int fd = -1;
     std::string in;              // received, not yet consumed
+    size_t in_off = 0;           // parse cursor into `in` (non-zero only inside Worker::parse)
     std::string out;             // serialised responses not yet sent
     size_t out_off = 0;
     int64_t last_ms = 0;         // last byte in or out
     int64_t req_start_ms = 0;    // first byte of the request being received (0: between requests)
     // the request whose body is still arriving
-    bool have_head = false, keep = false, want_continue = false;
+    bool have_head = false, keep = false, want_continue = false, big = false;     // big: counted in the worker's big_bodies_
     std::string method, target;
     size_t hdr_len = 0, clen = 0;
     bool close_after_send = false;   // answer, then close
@@ -79,11 +88,12 @@ class Worker {
         for (;;) {
             const int64_t t = now_ms();
             pfds.clear();
-            pfds.push_back(pollfd{ls_, (short)(t >= accept_pause_until_ ? POLLIN : 0), 0});
+            pfds.push_back(pollfd{ls_, (short)(t >= accept_pause_until_ && conns_.size() < kMaxConns ? POLLIN : 0), 0});
             int64_t wake = t + 1000;
             for (auto &c : conns_) {
                 short ev = 0;
-                if (!c.close_after_send || c.draining) ev |= POLLIN;        // (a connection about to be closed reads nothing more)
+                // (a connection about to be closed reads nothing more; one whose peer does not take its answers is not read either)
+                if (c.draining || (!c.close_after_send && pending(c) <= kMaxPendingOut)) ev |= POLLIN;
                 if (c.out_off < c.out.size()) ev |= POLLOUT;
                 pfds.push_back(pollfd{c.fd, ev, 0});
                 wake = std::min(wake, deadline_of(c));
@@ -103,11 +113,15 @@ class Worker {
                 const short re = pr > 0 ? pfds[i + 1].revents : 0;
                 bool alive = true;
                 if (re & (POLLIN | POLLHUP | POLLERR)) alive = on_readable(c, now);
-                if (alive && (re & POLLOUT)) alive = flush(c, now);
+                if (alive && (re & POLLOUT)) {
+                    alive = flush(c, now);
+                    if (alive && !c.draining && !c.in.empty()) alive = pump(c, now);      // requests held back by the output bound
+                }
                 if (alive && now >= deadline_of(c)) alive = false;          // request too slow, idle too long, drain over
                 if (!alive) {
                     ::close(c.fd);
                     c.fd = -1;
+                    if (c.big) big_bodies_--;
                 }
             }
             for (size_t i = 0; i < conns_.size();) {
@@ -128,7 +142,9 @@ class Worker {
     const Handler &handler_;
     std::vector<Conn> conns_;
     int64_t accept_pause_until_ = 0;
+    size_t big_bodies_ = 0;
 
+    static size_t pending(const Conn &c) { return c.out.size() - c.out_off; }
     static int64_t deadline_of(const Conn &c) {
         if (c.draining) return c.drain_until;
         if (c.req_start_ms) return c.req_start_ms + kRequestDeadlineMs;
@@ -136,7 +152,7 @@ class Worker {
     }
 
     void accept_some(int64_t now) {
-        for (int burst = 0; burst < 16; burst++) {
+        for (int burst = 0; burst < 16 && conns_.size() < kMaxConns; burst++) {
             int fd = ::accept(ls_, nullptr, nullptr);
             if (fd < 0) {
                 if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR || errno == ECONNABORTED) return;   // another worker took it / nothing left
@@ -229,26 +245,49 @@ class Worker {
             budget -= (size_t)k;
         }
         if (c.draining) return true;
-        parse(c);
-        if (c.peer_closed) {
-            if (c.out_off >= c.out.size()) return false;       // nothing left to say
-            c.close_after_send = true;                         // (an incomplete request of a peer that is gone is dropped with the connection)
-        }
-        return flush(c, now);
+        return pump(c, now);
     }
 
-    // consume every complete request in c.in
+    // Answer what c.in holds and send what can be sent, until the input has no complete request left or the peer is not
+    // taking its answers (kMaxPendingOut): a fast reader gets all its pipelined requests answered in this turn — nothing but
+    // a socket event would call parse() again, and none comes once the kernel's buffers are empty.  false: close now.
+    bool pump(Conn &c, int64_t now) {
+        bool blocked = false;
+        for (;;) {
+            const size_t before = c.in.size();
+            parse(c);
+            if (!flush(c, now)) return false;
+            if (c.draining || c.close_after_send) return true;
+            blocked = pending(c) > kMaxPendingOut;
+            if (blocked || c.in.empty() || c.in.size() == before) break;
+        }
+        if (c.peer_closed && !blocked) {                       // the peer is done sending and every complete request is answered
+            if (pending(c) == 0) return false;                 // nothing left to say
+            c.close_after_send = true;                         // (an incomplete request of a peer that is gone is dropped with the connection)
+        }
+        return true;
+    }
+
+    // consume every complete request in c.in.  Requests are taken from a cursor (c.in_off) and the consumed prefix is erased
+    // ONCE on the way out: erasing per request made a 4 MB burst of pipelined /status polls cost 120 000 memmoves of 4 MB.
     void parse(Conn &c) {
-        while (!c.close_after_send) {
+        parse_requests(c);
+        if (c.in_off) {
+            c.in.erase(0, c.in_off);
+            c.in_off = 0;
+        }
+    }
+    void parse_requests(Conn &c) {
+        while (!c.close_after_send && pending(c) <= kMaxPendingOut) {
             if (!c.have_head) {
-                const size_t he = c.in.find("\r\n\r\n");
+                const size_t he = c.in.find("\r\n\r\n", c.in_off);
                 if (he == std::string::npos) {
-                    if (c.in.size() > kMaxHeader) refuse(c, 431, "Request Header Fields Too Large", nullptr);
+                    if (c.in.size() - c.in_off > kMaxHeader) refuse(c, 431, "Request Header Fields Too Large", nullptr);
                     return;
                 }
                 if (!parse_head(c, he)) return;
             }
-            const size_t have = c.in.size() - c.hdr_len;
+            const size_t have = c.in.size() - c.in_off - c.hdr_len;
             if (have < c.clen) {
                 if (!c.want_continue) return;
                 c.out += "HTTP/1.1 100 Continue\r\n\r\n";
@@ -258,16 +297,20 @@ class Worker {
             Request rq;
             rq.method = std::move(c.method);
             rq.target = std::move(c.target);
-            if (c.in.size() == c.hdr_len + c.clen) {           // the usual case: nothing behind the body — no second copy of a large body
+            if (c.in_off == 0 && c.in.size() == c.hdr_len + c.clen) {           // the usual case: nothing before or behind the body — no second copy of a large body
                 c.in.erase(0, c.hdr_len);
                 rq.body = std::move(c.in);
                 c.in.clear();
             } else {
-                rq.body = c.in.substr(c.hdr_len, c.clen);
-                c.in.erase(0, c.hdr_len + c.clen);
+                rq.body = c.in.substr(c.in_off + c.hdr_len, c.clen);
+                c.in_off += c.hdr_len + c.clen;
             }
             c.have_head = false;
-            c.req_start_ms = c.in.empty() ? 0 : now_ms();
+            if (c.big) {
+                c.big = false;
+                big_bodies_--;
+            }
+            c.req_start_ms = c.in.size() == c.in_off ? 0 : now_ms();
             Response rs;
             try {
                 rs = handler_(std::move(rq));
@@ -284,9 +327,9 @@ class Worker {
         }
     }
 
-    // request line + headers of the request at the front of c.in; false: refused
+    // request line + headers of the request at the cursor of c.in (its header ends at absolute position he); false: refused
     bool parse_head(Conn &c, size_t he) {
-        const std::string head = c.in.substr(0, he);
+        const std::string head = c.in.substr(c.in_off, he - c.in_off);
         const size_t le = head.find("\r\n");
         const std::string reqline = head.substr(0, le);
         const size_t s1 = reqline.find(' '), s2 = reqline.rfind(' ');
@@ -327,7 +370,15 @@ class Worker {
             refuse(c, 413, "Request Entity Too Large", nullptr);
             return false;
         }
-        c.hdr_len = he + 4;
+        if (c.clen > kBigBody) {
+            if (big_bodies_ >= kMaxBigBodies) {          // this worker already buffers its share of large uploads
+                refuse(c, 503, "Service Unavailable", "too many large uploads in progress: retry");
+                return false;
+            }
+            c.big = true;
+            big_bodies_++;
+        }
+        c.hdr_len = he + 4 - c.in_off;
         c.have_head = true;
         c.want_continue = expect100;
         return true;

@@ -174,3 +174,100 @@ def test_malformed_and_hostile_requests_never_take_the_server_down(server):
     c.request("POST", "/echo", body=b"x" * 1234)
     r = c.getresponse()
     assert r.status == 200 and r.read() == b"1234"
+
+
+def test_a_client_that_never_reads_its_answers_costs_bounded_memory(server):
+    """Pipelined requests from a peer that does not read: once ~1 MB of answers is unsent the connection is no longer read
+    (kMaxPendingOut), so the client's sends stall in the kernel's buffers instead of growing the server's; other connections
+    are served meanwhile; and when the client finally reads, every request it got through is answered, in order."""
+    s = socket.create_connection(("127.0.0.1", server), timeout=5)
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 65536)
+    s.setblocking(False)
+    req = b"GET /status HTTP/1.1\r\nHost: x\r\n\r\n"
+    chunk = req * 2000                       # 68 kB of requests -> ~230 kB of answers
+    sent, stalled_since = 0, None
+    t_end = time.time() + 20
+    while time.time() < t_end and sent < (64 << 20):
+        try:
+            k = s.send(chunk[sent % len(req):] if sent % len(req) else chunk)       # (keep request boundaries aligned across partial sends)
+            sent += k
+            stalled_since = None
+        except BlockingIOError:
+            if stalled_since is None:
+                stalled_since = time.time()
+            elif time.time() - stalled_since > 1.0:
+                break                        # the server has stopped reading this connection
+            time.sleep(0.02)
+    assert stalled_since is not None and sent < (32 << 20), "the server kept reading %d bytes of requests from a peer that never reads" % sent
+    code, body, dt = status(server)
+    assert code == 200 and dt < 0.5         # the worker serves its other connections
+    # now read (on a second thread: the tail of the requests only fits once the server reads again): every request that got
+    # through is answered, in order, and the connection ends with the request that asked for it
+    import threading
+    whole = sent // len(req)
+    s.setblocking(True)
+    s.settimeout(20)
+    data = bytearray()
+
+    def drain():
+        while True:
+            k = s.recv(1 << 20)
+            if not k:
+                return
+            data.extend(k)
+
+    th = threading.Thread(target=drain)
+    th.start()
+    if sent % len(req):
+        s.sendall(req[sent % len(req):])     # complete the request that was cut
+        whole += 1
+    s.sendall(b"GET /status HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n")
+    th.join(30)
+    assert not th.is_alive() and data.count(b"HTTP/1.1 200 OK") == whole + 1
+
+
+def test_large_uploads_in_progress_are_limited_per_worker(server):
+    """At most kMaxBigBodies (4) bodies above 1 MB are buffered by one worker at a time: the fifth is answered 503 at its header."""
+    hold = []
+    try:
+        for _ in range(4):
+            c = socket.create_connection(("127.0.0.1", server), timeout=5)
+            c.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 900000\r\n\r\n" + b"x" * 10)       # below the big-body bound: not counted
+            hold.append(c)
+        # (max_body of this server is 1 000 000: bodies between 1 MB = 2^20 and that cannot exist here, so the bound is exercised
+        # through a second server instance below)
+    finally:
+        for c in hold:
+            c.close()
+    p2 = subprocess.Popen([EXE, "0"], stderr=subprocess.PIPE) if False else None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p2 = subprocess.Popen([EXE, str(port), "1", "64000000"], stderr=subprocess.PIPE)
+    try:
+        assert p2.stderr.readline().strip() == b"ready"
+        for _ in range(4):
+            c = socket.create_connection(("127.0.0.1", port), timeout=5)
+            c.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 2000000\r\n\r\n" + b"x" * 1000)
+            hold.append(c)
+        time.sleep(0.2)
+        c5 = socket.create_connection(("127.0.0.1", port), timeout=5)
+        c5.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 2000000\r\n\r\n")
+        assert c5.recv(65536).startswith(b"HTTP/1.1 503")
+        c5.close()
+        hold[-1].sendall(b"x" * (2000000 - 1000))            # one of the four completes: its place is free again
+        assert b"2000000" in hold[-1].recv(65536)
+        c6 = socket.create_connection(("127.0.0.1", port), timeout=5)
+        c6.sendall(b"POST /echo HTTP/1.1\r\nContent-Length: 1500000\r\n\r\n" + b"y" * 1500000)
+        buf = b""
+        while b"1500000" not in buf:
+            k = c6.recv(65536)
+            assert k
+            buf += k
+        c6.close()
+    finally:
+        for c in hold:
+            c.close()
+        p2.kill()
+        p2.wait()
