@@ -783,9 +783,12 @@ def server_leg():
     tool = os.path.join(ROOT, "tools", "server_bench.py")
     if not (os.path.exists(exe) and os.path.exists(tool)):
         return {"value": None, "error": "proverServer / tools/server_bench.py not built"}
+    # (without the OpenMP variables the CPU leg exported for the oracle: OMP_PROC_BIND pins a process that loads libgomp —
+    # the load generator's sixteen client threads then share one core and the "server" rate halves)
+    env = {kk: v for kk, v in os.environ.items() if not kk.startswith("OMP_")}
     try:
         r = subprocess.run([sys.executable, tool, "15", "512", "0", "witness", "semaphore"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                           timeout=150, text=True, cwd=ROOT)
+                           timeout=150, text=True, cwd=ROOT, env=env)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
             return {"value": None, "error": "server_bench rc %d" % r.returncode}

@@ -87,17 +87,79 @@ def _small_fr(rng, count, bits):
     return out
 
 
-def generate(k, n_public=2, seed=0, circuit_like=False):
+def _semaphore_like_circuit(m, n_in, n_public, rng, prng):
+    """Rows of a Semaphore-shaped R1CS in this generator's constraint form (a1 w_p + a2 w_q)(b1 w_u + b2) = w_out: a long chain
+    of hash "levels" as in a Merkle-path circuit — per level one boolean path bit (b*b), a two-constraint mux of the running hash
+    and a sibling (d = sib - cur, sel = b*d), one linear constraint forming the hash input, and ROUNDS rounds of an x^5 S-box with
+    a round constant (t1 = (x+k)^2, t2 = t1^2, y = t2*(x+k)), each round reading the previous one's output.  Published shape of
+    the Semaphore / iden3-auth class: almost every signal is a full-size field element, a few per cent are boolean selectors,
+    constraints depend on each other in chains thousands deep, every row has one or two non-zero coefficients per matrix.
+    -> (p, q, u, a1, a2, b1, b2) as in generate(), and the witness of the internal signals computed on the host in row order."""
+    ROUNDS = 30
+    one = 0                                        # signal 0 is the constant 1
+    P, Q, U, A1, A2, B1, B2 = ([0] * m for _ in range(7))
+    bits = list(range(1 + n_public, 1 + n_public + (n_in - n_public) // 2))            # boolean private inputs (path indices)
+    sibs = list(range(1 + n_public + (n_in - n_public) // 2, 1 + n_in))                 # full-size private inputs (siblings, secrets)
+    w_in = [0] * (1 + n_in)
+    w_in[0] = 1
+    for i in range(1, 1 + n_public):
+        w_in[i] = prng.randrange(R_MOD)
+    for i in bits:
+        w_in[i] = prng.randrange(2)
+    for i in sibs:
+        w_in[i] = prng.randrange(R_MOD)
+    val = list(w_in) + [0] * m                     # signal values; internal signal of row r is 1 + n_in + r
+
+    def row(r, a1, p, a2, q, b1, u, b2):
+        P[r], Q[r], U[r], A1[r], A2[r], B1[r], B2[r] = p, q, u, a1 % R_MOD, a2 % R_MOD, b1 % R_MOD, b2 % R_MOD
+        val[1 + n_in + r] = (a1 * val[p] + a2 * val[q]) % R_MOD * ((b1 * val[u] + b2) % R_MOD) % R_MOD
+        return 1 + n_in + r
+
+    r, level, cur = 0, 0, sibs[0]
+    while r < m:
+        b, sib = bits[level % len(bits)], sibs[(level + 1) % len(sibs)]
+        level += 1
+        if r + 4 >= m:                             # not enough rows left for a level: pad with boolean rows
+            row(r, 1, b, 0, one, 1, b, 0)
+            r += 1
+            continue
+        row(r, 1, b, 0, one, 1, b, 0)                                                    # b*b (= b: the boolean check's product)
+        d = row(r + 1, 1, sib, -1, cur, 0, one, 1)                                       # d = sib - cur          (linear)
+        sel = row(r + 2, 1, b, 0, one, 1, d, 0)                                          # sel = b * d
+        x = row(r + 3, 1, cur, 1, sel, 0, one, 1)                                        # x = cur + sel          (linear): the level's hash input
+        r += 4
+        for _ in range(ROUNDS):
+            if r + 3 > m:
+                break
+            kc = prng.randrange(R_MOD)
+            t1 = row(r, 1, x, kc, one, 1, x, kc)                                         # (x + k)^2
+            t2 = row(r + 1, 1, t1, 0, one, 1, t1, 0)                                     # (x + k)^4
+            x = row(r + 2, 1, t2, 0, one, 1, x, kc)                                      # (x + k)^5
+            r += 3
+        cur = x
+    to_rows = lambda xs: np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in xs), dtype=np.uint8).copy()
+    w_rows = to_rows(val[1:]).reshape(-1, 32)
+    return (np.array(P, np.uint32), np.array(Q, np.uint32), np.array(U, np.uint32), to_rows(A1), to_rows(A2), to_rows(B1), to_rows(B2),
+            w_rows[:n_in], w_rows[n_in:])
+
+
+def generate(k, n_public=2, seed=0, circuit_like=False, semaphore_like=False):
     """-> dict with the zkey sections (numpy uint8), the witness, the trapdoor and the vectors the
     trapdoor check needs.  Needs a GPU.
 
     circuit_like: what circom circuits look like instead of uniformly random everything — nVars = 3/4 of the domain + 5
     (never the domain size); 80 % of the signals boolean (inputs drawn from {0,1}, internal signals the AND of two boolean
     inputs), 15 % small (16-bit coefficients on small inputs), 5 % full-size; a second layer of constraints reads the first
-    layer's outputs; wires that never occur in A (or in B) leave all-zero rows = points at infinity in those tables."""
+    layer's outputs; wires that never occur in A (or in B) leave all-zero rows = points at infinity in those tables.
+
+    semaphore_like: the shape class of BASELINE configs[4] (Semaphore / iden3 auth; no such key exists in this image) — see
+    _semaphore_like_circuit: 64 inputs, nVars = 3/4 of the domain + 5, chains of x^5 S-box rounds between Merkle-style muxes,
+    nearly every signal a full-size field element; the witness is computed on the host (the constraints form one long chain)."""
     n = 1 << k
-    n_in = max(n_public + 1, n // 8)                 # input signals (incl. the public ones)
-    m = (3 * n // 4 + 5 if circuit_like else n) - 1 - n_in      # constraints = internal signals
+    n_in = 64 if semaphore_like else max(n_public + 1, n // 8)                 # input signals (incl. the public ones)
+    if semaphore_like and n_in < n_public + 8:
+        raise ValueError("semaphore_like needs at most 56 public signals")
+    m = (3 * n // 4 + 5 if (circuit_like or semaphore_like) else n) - 1 - n_in      # constraints = internal signals
     if m < 1 or m + n_public + 1 > n:
         raise ValueError("domain too small")
     n_vars = 1 + n_in + m                            # = n (circuit_like: 3n/4 + 5)
@@ -111,6 +173,9 @@ def generate(k, n_public=2, seed=0, circuit_like=False):
     a1, a2, b1, b2 = (synth.random_fr_bytes(rng, m).reshape(-1) for _ in range(4))          # standard values
     w_in = synth.random_fr_bytes(rng, n_in)
     layer2 = np.zeros(m, dtype=bool)
+    w_internal = None
+    if semaphore_like:
+        p, q, u, a1, a2, b1, b2, w_in, w_internal = _semaphore_like_circuit(m, n_in, n_public, rng, prng)
     if circuit_like:
         cls_in = rng.random(n_in)
         w_in[cls_in < 0.80] = _small_fr(rng, int((cls_in < 0.80).sum()), 1)
@@ -145,7 +210,7 @@ def generate(k, n_public=2, seed=0, circuit_like=False):
     recA = np.concatenate([_records(0, rows, p, a1m), _records(0, rows, q, a2m),
                            _records(0, extra_rows, np.arange(n_public + 1, dtype=np.uint32), np.tile(one_r2, n_public + 1))])
     recB = np.concatenate([_records(1, rows, u, b1m), _records(1, rows, np.zeros(m, np.uint32), b2m)])
-    if circuit_like:                                # a real zkey holds no zero coefficients
+    if circuit_like or semaphore_like:              # a real zkey holds no zero coefficients
         recA = recA[recA["v"].max(axis=1) > 0]
         recB = recB[recB["v"].max(axis=1) > 0]
     rec = np.concatenate([recA, recB])
@@ -156,10 +221,12 @@ def generate(k, n_public=2, seed=0, circuit_like=False):
     w = np.zeros((n_vars, 32), dtype=np.uint8)
     w[0, 0] = 1
     w[1:1 + n_in] = w_in
-    for _pass in range(2 if layer2.any() else 1):
+    for _pass in range(0 if w_internal is not None else (2 if layer2.any() else 1)):
         am, bm = L.fr_coef_accumulate(coefs, rec.size, n, w.reshape(-1))
         prod = _mul(_mul(am[:m * 32], bm[:m * 32]), _const(1, m))                            # (aR)(bR)/R /R = ab
         w[1 + n_in:] = prod.reshape(-1, 32)
+    if w_internal is not None:
+        w[1 + n_in:] = w_internal                    # the chain was evaluated row by row on the host
     w = w.reshape(-1)
 
     # ---- Fr half of the setup

@@ -105,6 +105,45 @@ def test_circuit_like_key_is_valid_sparse_and_verifies(zk):
     assert og.proof_to_json(pts) == zk.proof_to_json(want)
 
 
+def test_semaphore_like_key_is_valid_and_has_the_shape_it_claims(zk):
+    """zkgen.generate(semaphore_like=True) — the proxy for BASELINE configs[4]: 4 public signals, chains of x^5 S-box rounds
+    between Merkle-style muxes (constraints thousands deep), nearly every signal a full-size field element, one or two
+    coefficients per row and matrix — and a VALID key: GPU proof = toxic-waste prediction = C restatement, pairing check passes."""
+    from oracle import pairing
+    from rapidsnark_old_amd import zkgen, views
+    k, npub = 12, 4
+    key = zkgen.generate(k, npub, seed=2, semaphore_like=True)
+    nv = key["nVars"]
+    assert nv == 3 * (1 << k) // 4 + 5 and key["nPublic"] == 4
+    w = np.asarray(key["witness"]).reshape(nv, 32)
+    boolean = (w[:, 1:].max(axis=1) == 0) & (w[:, 0] <= 1)
+    full = w[:, 24:].max(axis=1) > 0
+    assert boolean.mean() < 0.1 and full.mean() > 0.85
+    rec = np.frombuffer(np.asarray(key["coefs"])[4:].tobytes(), dtype=synth_dtype())
+    assert (rec["v"].max(axis=1) > 0).all() and rec.size < 4 * nv          # sparse rows: < 2 coefficients per row and matrix on average
+    # the constraints really form a chain: the witness satisfies A.w o B.w = C.w row by row (checked through the operator)
+    am, bm = zk.fr_coef_accumulate(key["coefs"], rec.size, 1 << k, key["witness"])
+    m = nv - 1 - 64
+    one = np.tile(np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8), m)
+    ab = np.frombuffer(zk.fr_mul_vec(zk.fr_mul_vec(am[:m * 32], bm[:m * 32]), one), dtype=np.uint8).reshape(m, 32)      # (aR)(bR)/R/R = a b
+    assert (ab == w[65:]).all()
+    r, s = 0xFEEDFACE, (1 << 250) + 99
+    a, b, c = zkgen.expected_proof_dlogs(key, r, s)
+    pts = (bn.G1.mul(bn.G1.gen, a), bn.G2.mul(bn.G2.gen, b), bn.G1.mul(bn.G1.gen, c))
+    want = bn.g1_to_bytes(pts[0]) + bn.g2_to_bytes(pts[1]) + bn.g1_to_bytes(pts[2])
+    p = views.ProverFromView(zk, key, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=True)
+    assert p.prove_host(key["witness"], r, s) == want
+    p.lib.zk_prover_destroy(p.h)
+    assert co.prove(co.ZkeyView(key), key["witness"], r, s) == want
+    vkj = zkgen.verification_key(key)
+    vk = {"alpha1": tuple(int(x) for x in vkj["vk_alpha_1"][:2]), "IC": [tuple(int(x) for x in pt[:2]) for pt in vkj["IC"]]}
+    for name in ("beta2", "gamma2", "delta2"):
+        j = vkj["vk_%s_2" % name[:-1]]
+        vk[name] = ((int(j[0][0]), int(j[0][1])), (int(j[1][0]), int(j[1][1])))
+    pub = [int.from_bytes(w[i].tobytes(), "little") for i in range(1, npub + 1)]
+    assert pairing.groth16_verify(vk, pub, pts)
+
+
 def synth_dtype():
     from rapidsnark_old_amd import synth
     return synth.COEF_DTYPE

@@ -2,7 +2,7 @@
 """proverServer in throughput mode (BASELINE configs[4] shape): N concurrent /input requests against a
 trapdoor-valid 2^k key, proofs/s through the REST API.
 
-    python tools/server_bench.py [log2n=16] [requests=64] [workers=0] [route=input|witness]
+    python tools/server_bench.py [log2n=16] [requests=64] [workers=0] [route=input|witness] [key=random|semaphore]
 
 route = input: POST /input/:circuit, the reference's route (a witness-generator process per request: here a stub that
 copies the satisfying witness); route = witness: POST /witness/:circuit with the .wtns image as the body (no process, no
@@ -60,9 +60,12 @@ def main():
     nreq = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     workers = sys.argv[3] if len(sys.argv) > 3 else "0"
     route = sys.argv[4] if len(sys.argv) > 4 else "input"
+    shape = sys.argv[5] if len(sys.argv) > 5 else "random"
     from rapidsnark_old_amd import zkgen
     d = tempfile.mkdtemp(prefix="zksrv_")
-    key = zkgen.generate(k, 2, seed=1)
+    # key = semaphore: the Semaphore / iden3-auth SHAPE class (4 public signals, S-box chains between Merkle-style muxes, nearly
+    # every signal full-size) on a trapdoor-valid zkgen key — a proxy: no real Semaphore zkey exists in this image
+    key = zkgen.generate(k, 4, seed=1, semaphore_like=True) if shape == "semaphore" else zkgen.generate(k, 2, seed=1)
     zkgen.write_all(key, d)
     os.rename(os.path.join(d, "circuit.zkey"), os.path.join(d, "auth.zkey"))
     os.makedirs(os.path.join(d, "build"))
@@ -105,7 +108,8 @@ def main():
             ok += doc["status"] == "success"
             verified += doc.get("proof") == want
         dt = time.perf_counter() - t0
-        print(json.dumps({"log2n": k, "requests": nreq, "workers": workers, "route": post, "succeeded": ok, "proofs_equal_to_the_trapdoor_prediction": verified, "seconds": round(dt, 3),
+        print(json.dumps({"key": ("zkgen --semaphore-like proxy (nPublic 4, nVars %d; no real Semaphore / iden3-auth zkey in the image)" % key["nVars"]) if shape == "semaphore" else "zkgen random R1CS",
+                          "log2n": k, "requests": nreq, "workers": workers, "route": post, "succeeded": ok, "proofs_equal_to_the_trapdoor_prediction": verified, "seconds": round(dt, 3),
                           "proofs_per_s": round(nreq / dt, 1), "ms_per_proof": round(dt / nreq * 1e3, 2)}))
     finally:
         if srv.poll() is not None:

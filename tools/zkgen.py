@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """zkgen — write a trapdoor-VALID Groth16 key at a benchmark size (needs a GPU).
 
-    python tools/zkgen.py <log2n> <outdir> [--npublic N] [--seed S] [--circuit-like] [--prove]
+    python tools/zkgen.py <log2n> <outdir> [--npublic N] [--seed S] [--circuit-like | --semaphore-like] [--prove]
 
 Writes <outdir>/circuit.zkey, witness.wtns, verification_key.json, toxic.json (see
 rapidsnark-old_amd/zkgen.py).  --prove also runs the one-shot CLI `prover` on the written files with a
@@ -27,11 +27,13 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--prove", action="store_true")
     ap.add_argument("--circuit-like", action="store_true", help="nVars = 3/4 of the domain + 5, 80 %% boolean signals, all-zero table rows (zkgen.generate)")
+    ap.add_argument("--semaphore-like", action="store_true", help="the shape class of Semaphore / iden3 auth: chains of x^5 S-box rounds between Merkle-style muxes, "
+                                                                  "nearly every signal full-size (zkgen.generate; use --npublic 4)")
     args = ap.parse_args()
     import rapidsnark_old_amd as zk
     from rapidsnark_old_amd import zkgen, synth
     t = time.time()
-    key = zkgen.generate(args.log2n, args.npublic, args.seed, circuit_like=args.circuit_like)
+    key = zkgen.generate(args.log2n, args.npublic, args.seed, circuit_like=args.circuit_like, semaphore_like=args.semaphore_like)
     t_gen = time.time() - t
     t = time.time()
     zkgen.write_all(key, args.outdir)
