@@ -123,6 +123,10 @@ def main():
             if why_not:
                 src += "; in-run passes skipped: " + why_not
         finish_roofline(o, cs, src, counters.gather_ceiling(64, o["roofline"]["gather_table_bytes"]))
+    tag = os.environ.get("ZK_BENCH_SAVE_COUNTERS")          # tools/profile_bench.sh: keep this run's counter summaries for later replays
+    if tag and measured:
+        with open(os.path.join(ROOT, "profiles", "%s_counters.json" % tag), "w") as f:
+            json.dump({"source": how, "legs": {leg: {"config": legs[leg]["config"], "n_gpus": legs[leg]["n_gpus"], "summary": measured[leg]} for leg in measured}}, f, indent=1)
     for leg, key in (("2p22_circuit", "also_realistic"), ("2p20", "also_2p20")):
         if leg in legs and legs[leg] is not out:
             o = legs[leg]

@@ -261,10 +261,12 @@ def test_results_are_kept_for_their_owner_and_unfinished_jobs_are_never_dropped(
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", ["1", "4"])
-def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch):
-    """BASELINE configs[4] on a key of its size class: no Semaphore / iden3-auth zkey exists in the image, so the key is a
-    trapdoor-VALID random R1CS with a 2^15 domain (rapidsnark_old_amd.zkgen; Semaphore is ~2^14..2^16 constraints).
+@pytest.mark.parametrize("batch,shape", [("1", "circuit"), ("4", "semaphore")])
+def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch, shape):
+    """BASELINE configs[4] on a key of its size AND shape class: no Semaphore / iden3-auth zkey exists in the image, so the key
+    is a trapdoor-VALID R1CS with a 2^15 domain (rapidsnark_old_amd.zkgen; Semaphore is ~2^14..2^16 constraints) — once the
+    circuit-like preset (80 % boolean signals), once the semaphore-like one (4 public signals, S-box chains between
+    Merkle-style muxes, nearly every signal full-size).
     proverServer in throughput mode — two replicas on the box's GPU, queue of 64, ZKHIP_BATCH 1 and 4 — takes 64
     concurrent /input requests; with fixed (r, s) EVERY returned proof must be (i) the bytes the one-shot CLI writes for
     the same files and (ii) the proof whose discrete logs follow from the toxic waste (pairing-free trapdoor check).
@@ -272,8 +274,8 @@ def test_semaphore_class_throughput_every_proof_checked(zk, tmp_path, batch):
     import concurrent.futures
     from rapidsnark_old_amd import synth, zkgen
     k, nreq = 15, 64
-    key = zkgen.generate(k, 2, seed=3, circuit_like=True)        # nVars = 3/4 n + 5, 80 % boolean signals, all-zero rows in A / B1 / B2
-    assert key["nVars"] == 3 * (1 << k) // 4 + 5
+    key = zkgen.generate(k, 4, seed=3, semaphore_like=True) if shape == "semaphore" else zkgen.generate(k, 2, seed=3, circuit_like=True)
+    assert key["nVars"] == 3 * (1 << k) // 4 + 5            # both presets: nVars is never the domain size
     zkgen.write_all(key, str(tmp_path))
     os.rename(tmp_path / "circuit.zkey", tmp_path / "auth.zkey")
     r, s = 0x0F1E2D3C4B5A6978, (1 << 231) + 4242
