@@ -208,14 +208,23 @@ struct Fp29 {
     //         result the next instruction reads);
     //   run1: one job, its operand products and its reduction products as two interleaved chains merged by one
     //         64-bit add per column (a product that has no independent sibling).
-    // Per product: 162 MADs + 17 shifts + 9 v_mul_lo + 17 masks (+ 17 adds in run1).
+    // Per product: 162 MADs + 17 shifts + 9 v_mul_lo + 10 masks (+ 17 adds in run1).
     // masked limb of a result.  C column sums only: the mask tells the optimiser the limb is non-negative (see from_words)
     ZK_HD static int32_t out_limb(int64_t acc) {
         int32_t v = (int32_t)((uint32_t)acc & (uint32_t)MASK);
         ZK_SIGN_BARRIER(v);
         return v;
     }
-    ZK_HD static int32_t mont_m(int64_t acc) { return (int32_t)(((uint32_t)acc * N0INV) & (uint32_t)MASK); }
+    // The reduction digit of a column: any m = acc * (-p^-1) (mod 2^29) clears the column's low 29 bits.  Only the TOP digit
+    // (column 8) is masked to 29 bits; the lower ones stay the signed 32-bit product as it comes out of v_mul_lo_u32: their three
+    // extra bits act as a carry into the next digit (which is computed from the running sum and absorbs it), the value of
+    // M = sum m_i 2^(29 i) — and with it the output range — is set by the masked top digit alone, and eight v_and per product go
+    // away.  Column bound with |m_i| < 2^31: the reduction terms add up to at most 2^31 * (sum of the modulus limbs) = 3.47e18 (Fq) /
+    // 3.92e18 (Fr) beside at most 18 operand terms of (2^29 + 16)^2, or 9 of (2^29 + 16)(2^30 + 32), = 5.19e18: below 2^63 = 9.22e18.
+    ZK_HD static int32_t mont_m(int64_t acc, bool top) {
+        const uint32_t m = (uint32_t)acc * N0INV;
+        return top ? (int32_t)(m & (uint32_t)MASK) : (int32_t)m;
+    }
     ZK_HD static constexpr int col_lo(int k) { return k < 9 ? 0 : k - 8; }
     ZK_HD static constexpr int col_n(int k) { return k < 9 ? k + 1 : 17 - k; }          // a_i * b_(k-i) terms of column k
     struct JMul {                       // a * b
@@ -328,8 +337,8 @@ struct Fp29 {
         if constexpr (nr > 0) zk_blk_dmp(nr < 8 ? nr : 8, acc0, acc1, m0 + rlo, m1 + rlo, pr);
         if constexpr (nr > 8) zk_blk_dmp(nr - 8, acc0, acc1, m0 + rlo + 8, m1 + rlo + 8, pr + 8);
         if constexpr (K < 9) {
-            m0[K] = mont_m(acc0);
-            m1[K] = mont_m(acc1);
+            m0[K] = mont_m(acc0, K == 8);
+            m1[K] = mont_m(acc1, K == 8);
             zk_blk_dmp1(acc0, acc1, m0[K], m1[K], PS(0));
         } else {
             r0.l[K - 9] = out_limb(acc0);
@@ -372,9 +381,9 @@ struct Fp29 {
         if constexpr (nr > 0) zk_blk_tmp(nr < 6 ? nr : 6, acc0, acc1, acc2, m0 + rlo, m1 + rlo, m2 + rlo, pr);
         if constexpr (nr > 6) zk_blk_tmp(nr - 6, acc0, acc1, acc2, m0 + rlo + 6, m1 + rlo + 6, m2 + rlo + 6, pr + 6);
         if constexpr (K < 9) {
-            m0[K] = mont_m(acc0);
-            m1[K] = mont_m(acc1);
-            m2[K] = mont_m(acc2);
+            m0[K] = mont_m(acc0, K == 8);
+            m1[K] = mont_m(acc1, K == 8);
+            m2[K] = mont_m(acc2, K == 8);
             zk_blk_tmp1(acc0, acc1, acc2, m0[K], m1[K], m2[K], PS(0));
         } else {
             r0.l[K - 9] = out_limb(acc0);
@@ -414,8 +423,8 @@ struct Fp29 {
                 acc1 = zk_mad_s(acc1, m1[i], PS(k - i));
             }
             if (k < 9) {
-                m0[k] = mont_m(acc0);
-                m1[k] = mont_m(acc1);
+                m0[k] = mont_m(acc0, k == 8);
+                m1[k] = mont_m(acc1, k == 8);
                 acc0 = zk_mad_s(acc0, m0[k], PS(0));
                 acc1 = zk_mad_s(acc1, m1[k], PS(0));
             } else {
@@ -461,7 +470,7 @@ struct Fp29 {
             for (int i = (k < 9 ? 0 : k - 8); i < (k < 9 ? k : 9); i++) acc = zk_mad_s(acc, m[i], PS(k - i));
 #endif
             if (k < 9) {
-                m[k] = mont_m(acc);
+                m[k] = mont_m(acc, k == 8);
                 acc = zk_mad_s(acc, m[k], PS(0));
             } else {
                 r.l[k - 9] = out_limb(acc);

@@ -46,7 +46,7 @@ __device__ __forceinline__ void f2_columns(F2 &r, const F2 &x, const F2 &y, bool
             acc1 += (int64_t)m1[i] * F::PS(k - i);
         }
         if (k < 9) {
-            m0[k] = F::mont_m(acc0); m1[k] = F::mont_m(acc1);
+            m0[k] = F::mont_m(acc0, k == 8); m1[k] = F::mont_m(acc1, k == 8);
             acc0 += (int64_t)m0[k] * F::PS(0); acc1 += (int64_t)m1[k] * F::PS(0);
         } else {
             r.a.l[k - 9] = F::out_limb(acc0); r.b.l[k - 9] = F::out_limb(acc1);
