@@ -254,6 +254,10 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
         memset(&b, 0, sizeof b);
         b.n = 3;
         b.points[0] = p->ptsA.p; b.points[1] = p->ptsB1.p; b.points[2] = p->ptsC.p;
+        // ZKHIP_PROBE_ONE_TABLE=1 (-DZK_PROBES builds only; wrong sums): all three MSMs of the launch gather from table A — the same
+        // instruction stream and gather count out of a 3.25 GiB footprint instead of 9.75 GiB (profiles/NEGATIVE_RESULTS.md item 18)
+        static const bool one_table = probe_env("ZKHIP_PROBE_ONE_TABLE") != nullptr;
+        if (one_table) b.points[1] = b.points[2] = p->ptsA.p;
         b.idx_min[2] = b.idx_sub[2] = p->c_idx_min;
         b.bucket_stride = tbw;
         b.ws_stride = q.acc_stride;
