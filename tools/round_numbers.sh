@@ -19,7 +19,7 @@ python tools/shard_probe.py 22 1,2,4,8 2>&1 | grep world > $out/${tag}_shard_pro
 python tools/cli_timing.py 22 /tmp/zk_cli 2 2>&1 | grep -v amdgpu > $out/${tag}_cli_timing_2p22.txt
 bash tools/ntt_counters.sh ${tag}_ntt 22 > /dev/null 2>&1; cp gpurun_out/${tag}_ntt/summary.txt $out/${tag}_ntt_pipeline_counters.txt
 tools/mul_rate_probe > $out/${tag}_mul_rate.txt 2>&1
-for f in $out/*.json; do python - "$f" <<'PY'
+for f in $out/*bench*.json; do python - "$f" <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
