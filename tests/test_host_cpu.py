@@ -223,3 +223,19 @@ def test_tail_pool_runs_every_item_once_under_concurrent_callers(tmp_path):
     if subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", inc, src, "-o", tsan], capture_output=True).returncode == 0:
         out = subprocess.run([tsan, "6", "800"], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "ThreadSanitizer" not in out.stderr and " 0 wrong counts" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_column_bounds_of_the_29_bit_limb_products():
+    """field29.hpp's Montgomery products accumulate a whole column in ONE signed 64-bit register.  With the lower eight reduction
+    digits left as signed 32-bit values (only the top one is masked) a column holds, at worst, the operand terms the callers'
+    limb bounds allow PLUS 2^31 x (sum of the modulus limbs): it must stay below 2^63 for both fields and every job shape."""
+    src = open(os.path.join(ROOT, "rapidsnark-old_amd", "csrc", "field29.hpp")).read()
+    for name, mod in (("Fq29Params", bn.Q_MOD), ("Fr29Params", bn.R_MOD)):
+        limbs = [(mod >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
+        decl = re.search(r"struct %s \{.*?P\[9\] = \{([^}]*)\}" % name, src, re.S).group(1)
+        assert [int(x) for x in decl.split(",")] == limbs                     # the header's limbs ARE the modulus
+        reduction = (1 << 31) * sum(limbs)
+        tight, wide = (1 << 29) + 16, (1 << 30) + 32
+        assert reduction + 18 * tight * tight + (1 << 35) < 1 << 63           # a*b + c*d (and the four-product job: <= 18 terms of one sign)
+        assert reduction + 9 * tight * wide + (1 << 35) < 1 << 63             # a*b with ONE lazily added operand (DIT butterflies)
+        assert reduction + (4 * wide * tight + tight * tight) + (1 << 35) < 1 << 63      # a^2 with the doubled operand
