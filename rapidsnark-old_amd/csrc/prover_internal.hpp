@@ -152,7 +152,13 @@ struct SortBufs {
         bin_counts.alloc(z.bin_counts_u32);
         bin_starts.alloc(z.bin_starts_u32);
     }
+    bool ran = false;
     void run(const Fr *scalars, hipStream_t s) {
+        // ZKHIP_PROBE_SKIP_SORT=1 (-DZK_PROBES builds only; wrong sums): the sort runs once per buffer set and its result is reused —
+        // what a proof costs if digits + counting sort were free (profiles/NEGATIVE_RESULTS.md item 22)
+        static const bool skip = probe_env("ZKHIP_PROBE_SKIP_SORT") != nullptr;
+        if (skip && ran) return;
+        ran = true;
         MsmSortBufs b{offsets.p, entries.p, counts.p, starts.p, codes.p, val.p, bin_counts.p, bin_starts.p, lo.p};
         launch_msm_sort(b, scalars, n, plan, s);
     }
