@@ -84,11 +84,8 @@ std::vector<int> workerDevicesFromEnv() {
 
 }   // namespace
 
-// depth per replica: three proofs in flight saturate the GPU on large circuits (and each costs GiBs of
-// workspace); small circuits are latency-bound per proof and want the maximum
-static size_t depthFor(uint32_t domainSize) {
-    return domainSize > (1u << 22) ? 3 : (domainSize >= (1u << 19) ? 6 : ZK_MAX_IN_FLIGHT);
-}
+// (depth per replica: what the library plans for the prover — zk_prover_info through makeProver(..., kLibraryDepth): three proofs in
+// flight saturate the GPU on large circuits, and each costs GiBs of workspace; small circuits are latency-bound and want the maximum)
 
 FullProver::FullProver(std::string zkeyFileNames[], int size) {
     workerDevices = workerDevicesFromEnv();
@@ -115,7 +112,7 @@ FullProver::FullProver(std::string zkeyFileNames[], int size) {
         }
         // every slot and lane the pipeline will walk is allocated at start-up (an out-of-memory there falls back to the tables
         // as in the zkey, or ends the start — never a proof later)
-        const uint32_t reserve = queueMode() ? (uint32_t)depthFor(hdr->domainSize) : 1u;
+        const uint32_t reserve = queueMode() ? Groth16::kLibraryDepth : 1u;
         for (int dev : workerDevices)
             c.replica.push_back(Groth16::makeProver(hdr->nVars, hdr->nPublic, hdr->domainSize, hdr->nCoefs, hdr->vk_alpha1, hdr->vk_beta1,
                                                     hdr->vk_beta2, hdr->vk_delta1, hdr->vk_delta2, zkey->getSectionData(4),
@@ -474,7 +471,7 @@ void FullProver::deviceLoop(size_t worker) {
             readyJobs.pop_front();
             jobs.push_back(job);
         }
-        size_t depth = depthFor(circuits[job->circuit].header->domainSize);
+        size_t depth = ZK_MAX_IN_FLIGHT;            // (a replica always reports what start-up reserved: the library's depth, or what fitted)
         if (const uint32_t fits = circuits[job->circuit].replica[worker]->reservedInFlight()) depth = std::min(depth, (size_t)fits);
         {
             std::unique_lock<std::mutex> lk(wm);

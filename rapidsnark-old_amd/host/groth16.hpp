@@ -97,6 +97,10 @@ public:
     }
 };
 
+// makeProver(..., reserveInFlight = kLibraryDepth): reserve the pipeline depth zk_prover_info recommends for the prover just created
+// (host witnesses) instead of a number the caller derived from the circuit's size
+static const uint32_t kLibraryDepth = 0xFFFFFFFFu;
+
 // "0,1,2,3" -> {0,1,2,3}
 inline std::vector<int32_t> parseDeviceList(const char *s) {
     std::vector<int32_t> v;
@@ -177,6 +181,12 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     auto create = [&](uint32_t reserve) {
         int rc = zk_prover_create(&h, &v, &o);
         if (rc != 0 || !reserve) return rc;
+        if (reserve == kLibraryDepth) {          // the depth that saturates THIS prover, as the library planned it (zk_prover_info)
+            zk_prover_plan plan;
+            memset(&plan, 0, sizeof plan);
+            plan.size = sizeof plan;
+            reserve = zk_prover_info(h, &plan) == 0 && plan.depth_host_witness ? plan.depth_host_witness : 3;
+        }
         rc = zk_prover_reserve(h, reserve, 1);
         if (rc == 0) {
             reserved = reserve;
@@ -206,7 +216,7 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     }
     // ... and where even then the workspace of a pipeline does not fit: one proof at a time (the caller reads the depth
     // it may use from reservedInFlight())
-    if (rc != 0 && reserveInFlight > 1 && oom()) {
+    if (rc != 0 && reserveInFlight > 1 && oom()) {      // (kLibraryDepth included)
         std::cerr << "the workspace of two proofs in flight does not fit the GPU's free memory: one proof at a time\n";
         rc = create(1);
     }
