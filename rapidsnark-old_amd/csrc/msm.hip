@@ -557,6 +557,80 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
         if (base + j < total) offsets[base + j] += add;
 }
 
+// Second-level scatter, STAGED: the direct version above sends every entry to L2 as a 4-byte request of its own (54.5 M requests per
+// sort at 2^22: 55 % of its wave cycles stalled at issue, profiles/r05u_sort_kernel_counters.txt).  Here a workgroup takes its slice of
+// the bin in tiles of STAGE_CAP entries, counting-sorts a tile INSIDE LDS (rank by LDS atomic, exclusive scan of the 2^11 bucket counts,
+// placement), and writes it out in bucket order: the entries of one bucket go to consecutive addresses, so consecutive lanes store
+// consecutive dwords and the address path merges them — about one request per (tile, bucket) run instead of one per entry.  The global
+// position of a run is the slice's cursor of that bucket (from the scan over (bucket, slice) counts, as before), advanced tile by tile.
+// For bins of at most 2^11 buckets and SORT_THREADS = 1024 (= SCAN_BLOCK); other plans keep the direct kernel.
+#ifndef STAGE_CAP
+#define STAGE_CAP 8192u
+#endif
+__global__ __launch_bounds__(SCAN_BLOCK) void k_bin_scatter_staged(uint32_t *entries, const uint32_t *starts, const uint16_t *lo, const uint32_t *val,
+                                                                   const uint32_t *bin_starts, uint32_t nblocks, uint32_t buckets_per_bin, uint32_t nbins,
+                                                                   uint32_t slices, uint32_t total_buckets) {
+    ZK_CHAIN_PRIO();
+    extern __shared__ uint32_t sm[];
+    uint32_t b, slice;
+    if (!bin_slice_of_block(nbins, slices, b, slice)) return;
+    const uint32_t first = b * buckets_per_bin, nb = total_buckets - first < buckets_per_bin ? total_buckets - first : buckets_per_bin;
+    uint32_t *loc = sm;                               // [2048] rank counters of the tile, then its exclusive bucket offsets
+    uint32_t *gcur = sm + 2048;                       // [2048] this slice's global cursor per bucket
+    uint32_t *scan_lds = sm + 4096;                   // [16]
+    uint32_t *sval = sm + 4096 + 16;                  // [STAGE_CAP]
+    uint16_t *slo = (uint16_t *)(sval + STAGE_CAP);   // [STAGE_CAP]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *in = starts + (uint64_t)first * slices + slice;
+    for (uint32_t k = tid; k < 2048u; k += SCAN_BLOCK) gcur[k] = k < nb ? in[(uint64_t)k * slices] : 0u;
+    const uint64_t bs = bin_starts[(uint64_t)b * nblocks], be = bin_starts[(uint64_t)(b + 1) * nblocks];
+    const uint64_t len = be - bs, s0 = bs + len * slice / slices, s1 = bs + len * (slice + 1) / slices;
+    constexpr uint32_t PER = STAGE_CAP / SCAN_BLOCK;  // entries per thread and tile
+    for (uint64_t t0 = s0; t0 < s1; t0 += STAGE_CAP) {
+        const uint32_t cnt = (uint32_t)(s1 - t0 < STAGE_CAP ? s1 - t0 : STAGE_CAP);
+        loc[tid] = 0;
+        loc[tid + SCAN_BLOCK] = 0;
+        __syncthreads();                              // (also: the previous tile's write-out has read loc / sval)
+        uint32_t key[PER], v[PER], rank[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t p = k * SCAN_BLOCK + tid;
+            key[k] = p < cnt ? lo[t0 + p] : 0xFFFFFFFFu;
+            v[k] = p < cnt ? val[t0 + p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) rank[k] = key[k] != 0xFFFFFFFFu ? atomicAdd(&loc[key[k]], 1u) : 0u;
+        __syncthreads();
+        // exclusive scan of the 2048 counts: two per thread
+        const uint32_t c0 = loc[2 * tid], c1 = loc[2 * tid + 1];
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(c0 + c1, scan_lds, total);
+        __syncthreads();
+        loc[2 * tid] = ex;
+        loc[2 * tid + 1] = ex + c0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (key[k] != 0xFFFFFFFFu) {
+                const uint32_t pos = loc[key[k]] + rank[k];
+                sval[pos] = v[k];
+                slo[pos] = (uint16_t)key[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = tid; p < cnt; p += SCAN_BLOCK) {
+            const uint32_t kk = slo[p];
+            entries[gcur[kk] + (p - loc[kk])] = sval[p];
+        }
+        __syncthreads();
+        // advance the cursors by the tile's counts: count of bucket k = loc[k + 1] - loc[k] (cnt - loc[k] for the last one)
+        const uint32_t a0 = loc[2 * tid], a1 = loc[2 * tid + 1], a2 = 2 * tid + 2 < 2048u ? loc[2 * tid + 2] : cnt;
+        gcur[2 * tid] += a1 - a0;
+        gcur[2 * tid + 1] += a2 - a1;
+        __syncthreads();                              // the next tile zeroes loc in another thread-to-word pattern
+    }
+}
+
 // ---------------------------------------------------------------- load-balanced accumulation
 // A lane-per-bucket walk is hopeless on real data: the top window of uniformly random
 // scalars has only a handful of non-empty buckets (r ~ 2^253.6), and real witnesses pile
@@ -1173,6 +1247,7 @@ static void sort_lds_attr() {
     ZK_HIP(hipFuncSetAttribute((const void *)k_bin_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(hipFuncSetAttribute((const void *)k_bin_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr.done();
 }
 
@@ -1182,7 +1257,14 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
     sort_lds_attr();
     uint64_t g = (n + 255) / 256;
     if (g > 8192) g = 8192;
-    const uint32_t sh = plan_bin_shift(p), nbins = plan_nbins(p), nblocks = plan_bin_blocks(n, p), slices = BIN_SLICES;
+    const uint32_t sh = plan_bin_shift(p), nbins = plan_nbins(p), nblocks = plan_bin_blocks(n, p);
+    // second-level workgroups per bin: about one staging tile of entries each (longer runs per bucket = fewer, wider stores), at most
+    // BIN_SLICES (what the count / start arrays are sized for), at least 4
+    uint32_t slices = BIN_SLICES;
+    {
+        const uint64_t per_bin = (n * p.W) / (nbins ? nbins : 1);
+        while (slices > 4u && per_bin / slices < STAGE_CAP * 3u / 4u) slices >>= 1;
+    }
     const uint32_t bpb = tb < (1u << sh) ? tb : (1u << sh);
     const uint64_t total = n * p.W;
     const size_t lds = (size_t)bpb * 4;
@@ -1196,8 +1278,14 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
     hipLaunchKernelGGL(k_bin_count_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
                        (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
     launch_scan(b.starts, b.counts, tb * slices, s);
-    hipLaunchKernelGGL(k_bin_scatter_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
-                       (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
+    static const bool direct = probe_env("ZKHIP_SORT_DIRECT") != nullptr;      // (-DZK_PROBES builds: the unstaged second-level scatter, for A/Bs)
+    if (bpb <= 2048u && SORT_THREADS == SCAN_BLOCK && !direct)
+        hipLaunchKernelGGL(k_bin_scatter_staged, dim3(grid2), dim3(SCAN_BLOCK), (size_t)(4096 + 16 + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2, s, b.entries,
+                           (const uint32_t *)b.starts, (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins,
+                           slices, tb);
+    else
+        hipLaunchKernelGGL(k_bin_scatter_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
+                           (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
     hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb, slices);
     ZK_LAUNCH_OK("msm sort");
 }
