@@ -24,7 +24,7 @@ def test_counters_are_replayed_from_the_committed_passes_when_they_cannot_be_mea
     config, _ = _config()
     cs, src = counters.replay(config, 1)
     assert "replayed from" in src and "not measured by this run" in src
-    assert cs["valu_instructions_per_proof"] > 15.0e9 and 4.0e9 < cs["g1_hbm_bytes_per_msm"] < 5.5e9 and 3.5e9 < cs["g2_hbm_bytes_per_launch"] < 5.0e9
+    assert 13.0e9 < cs["valu_instructions_per_proof"] < 16.0e9 and 4.0e9 < cs["g1_hbm_bytes_per_msm"] < 5.5e9 and 3.5e9 < cs["g2_hbm_bytes_per_launch"] < 5.0e9
     # another configuration has no pass of its own: nothing is replayed, nothing is invented
     none, why = counters.replay(dict(config, log2n=19, window_bits=17), 1)
     assert none is None and "no counter pass" in why
