@@ -122,7 +122,7 @@ def summarize_leg(kernels):
     if have_valu:
         tot = sum(v.get("SQ_INSTS_VALU", 0.0) for v in work.values())
         s["valu_instructions_per_proof"] = int(tot / proofs)
-        top = sorted(((v.get("SQ_INSTS_VALU", 0.0), k) for k, v in work.items()), reverse=True)[:6]
+        top = sorted(((v.get("SQ_INSTS_VALU", 0.0), k) for k, v in work.items()), reverse=True)[:14]
         s["valu_share"] = {k: round(x / tot, 4) for x, k in top if tot}
         s["g1_valu_per_msm"] = int(sum(v.get("SQ_INSTS_VALU", 0.0) for v in g1) / (4 * proofs)) if g1 else None
         s["g2_valu_per_launch"] = int(sum(v.get("SQ_INSTS_VALU", 0.0) for v in g2) / proofs) if g2 else None

@@ -42,7 +42,8 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp, uint32_t b
         if (c == 0) {
             c = lg > 2 ? lg - 2 : 2;
             if (lg == 20) c = 19;     // 14 windows instead of 15 pay for four times the buckets only here (2^20: 9.40 -> 9.16 ms per proof;
-                                      // 2^16 .. 2^19 and 2^21 measured neutral or worse with a wider window)
+                                      // 2^16 .. 2^19 measured neutral or worse with a wider window)
+            if (lg == 21) c = 20;     // 13 instead of 14: pays since the split bucket reduction (17.0 -> 16.55 ms, profiles/r05ze_window_sweep.txt)
             if (batch > 1) c++;       // a batch shares the fixed costs of a set of launches: one window fewer pays (2^16 x 8: 0.76 -> 0.69 ms per proof)
         }
         if (c > 20) c = 20;
@@ -1020,10 +1021,33 @@ __global__ __launch_bounds__(256) void k_msm_accum_wave(ACCMEM *buckets, const A
     }
 }
 
+// Large bucket sets, first level: lane t of a set takes the buckets t*chunk .. t*chunk + chunk - 1, so that
+// (k+1) = t*chunk + (j+1) splits  sum_k (k+1) B_k  =  chunk * sum_t t*T_t  +  sum_t A_t   with T_t = sum_j B[t*chunk+j] and
+// A_t = sum_j (j+1)*B[t*chunk+j]: two additions per bucket and NO per-lane scalar multiplication (the chunked form below
+// pays ~28 point operations per lane for lo*T on top of its 32).  sum_t t*T_t is the same problem on the L - 1 points
+// T_1 .. T_(L-1) (stored shifted by one; the chunked form finishes it), the A_t are a plain tree sum.
+template <class F>
+__global__ __launch_bounds__(128) void k_msm_reduce_split(ACCMEM *A, uint32_t a_stride, ACCMEM *T, const ACCMEM *buckets, uint32_t nbuckets, uint32_t chunk, uint32_t L) {
+    ZK_TAIL_PRIO();
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LM::LPE;
+    if (t >= L) return;
+    const ACCMEM *B = buckets + (uint64_t)blockIdx.y * nbuckets + (uint64_t)t * chunk;
+    XYZZ<FR> run = XYZZ<FR>::inf(), sum = XYZZ<FR>::inf();
+    for (int j = (int)chunk - 1; j >= 0; j--) {
+        add(run, LM::load(B + j));
+        add(sum, run);
+    }
+    LM::store(A + (uint64_t)blockIdx.y * a_stride + t, sum);
+    if (t == 0) run = XYZZ<FR>::inf();                                     // weight 0; its slot is the (empty) last one
+    LM::store(T + (uint64_t)blockIdx.y * L + (t ? t - 1 : L - 1), run);
+}
+
 // Lane per chunk of REDUCE_CHUNK buckets: running sums give A = sum (j+1)*B[lo+j], T = sum B;
 // X = A + lo*T is the chunk's share of sum_k (k+1)*B_k.
 template <class F>
-__global__ __launch_bounds__(128) void k_msm_reduce_chunks(ACCMEM *scratch, const ACCMEM *buckets, uint32_t nbuckets,
+__global__ __launch_bounds__(128) void k_msm_reduce_chunks(ACCMEM *scratch, uint32_t out_stride, const ACCMEM *buckets, uint32_t nbuckets,
                                                            uint32_t chunk, uint32_t total_chunks) {
     ZK_TAIL_PRIO();
     typedef LaneModel<F> LM;
@@ -1048,7 +1072,7 @@ __global__ __launch_bounds__(128) void k_msm_reduce_chunks(ACCMEM *scratch, cons
         }
         add(sum, m);
     }
-    LM::store(scratch + t, sum);
+    LM::store(scratch + (uint64_t)(t / chunks_per_window) * out_stride + cw, sum);      // (out_stride = chunks per set: back to back)
 }
 
 // Tree sum of `count` consecutive points per group, 2 inputs per lane + an LDS tree per workgroup:
@@ -1085,6 +1109,45 @@ __global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_tree(ACCMEM *out,
         const uint64_t at = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
         if (last) LM::store256(out_final + at, acc);    // window sums: canonical words, back in the zkey's 2^256 form
         else LM::store(out + at, acc);
+    }
+}
+
+// Last launch of the split form: per set, the partial sums of the shares X (cnt_x points at P) and of the A level (cnt_a
+// points behind them) are summed in the two halves of ONE LDS tree;  window sum = 2^scale_log * sum X + sum A.
+template <class F>
+__global__ __launch_bounds__(REDUCE_THREADS) void k_msm_reduce_final2(XYZZ<F> *out_final, const ACCMEM *P, uint32_t cnt_x, uint32_t cnt_a, uint32_t scale_log) {
+    ZK_TAIL_PRIO();
+    extern __shared__ uint32_t lds_raw[];
+    typedef LaneModel<F> LM;
+    typedef typename LM::R FR;
+    constexpr uint32_t H = REDUCE_THREADS / LM::LPE / 2;        // elements per half: 2H inputs each
+    XYZZ<FR> *lds = reinterpret_cast<XYZZ<FR> *>(lds_raw);
+    const uint32_t e = threadIdx.x / LM::LPE;
+    const bool xs = e >= H;                                      // upper half: the shares X;  lower half: A
+    const uint32_t eh = xs ? e - H : e, cnt = xs ? cnt_x : cnt_a;
+    const ACCMEM *in = P + (uint64_t)blockIdx.x * (cnt_x + cnt_a) + (xs ? 0u : cnt_x);
+    XYZZ<FR> acc = XYZZ<FR>::inf();
+    if (eh < cnt) acc = LM::load(in + eh);
+    if (eh + H < cnt) add(acc, LM::load(in + eh + H));
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = H / 2; s > 0; s >>= 1) {
+        if (eh < s) {
+            XYZZ<FR> o = lds[threadIdx.x + s * LM::LPE];
+            add(acc, o);
+            lds[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (xs && eh == 0) {
+        for (uint32_t i = 0; i < scale_log; i++) acc = dbl(acc);
+        lds[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (e == 0) {
+        XYZZ<FR> o = lds[threadIdx.x + H * LM::LPE];
+        add(acc, o);
+        LM::store256(out_final + blockIdx.x, acc);
     }
 }
 
@@ -1186,16 +1249,46 @@ static inline uint32_t reduce_chunk_for(MsmPlan p) {
     return p.nbuckets < chunk ? p.nbuckets : chunk;
 }
 
-// scratch: chunk sums + the intermediate levels of the tree (a geometric tail)
-uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
-    if (reduce_bits_for(p)) return (uint64_t)n_msm * p.sets * (p.nbuckets / 128u + 1u) * BITS_RS;      // block records (G2 blocks are the smaller)
-    uint64_t groups = (uint64_t)n_msm * p.sets, cnt = p.nbuckets / reduce_chunk_for(p), total = 0;
+// Buckets per lane of k_msm_reduce_split (0: the chunked form alone).  Sets of 2^14 buckets and more: below that a launch is
+// a handful of waves and the chunked form's depth is what counts.  ZKHIP_REDUCE_SPLIT overrides (tuning aid; 0 = off).
+#define REDUCE_SPLIT 16u
+// chunk of the chunked form on the T level (L points per set): 8 where that leaves whole tree workgroups of shares, else 4
+// (2^22 / 2^20, periods with 8 against 4: -0.6 % / -0.5 %, profiles/r05zd_split_parameters.txt)
+static inline uint32_t reduce_split_top(uint32_t L) {
+    static const uint32_t forced = [] { const char *e = probe_env("ZKHIP_REDUCE_SPLIT_TOP"); const uint32_t t = e ? (uint32_t)atoi(e) : 0u; return t >= 2u && (t & (t - 1)) == 0 ? t : 0u; }();
+    if (forced) return forced;
+    return (L / 8u) % (2u * REDUCE_THREADS) == 0 ? 8u : 4u;
+}
+static inline uint32_t reduce_split_for(MsmPlan p) {
+    static const int forced = [] { const char *e = probe_env("ZKHIP_REDUCE_SPLIT"); return e ? atoi(e) : -1; }();
+    if (reduce_bits_for(p) || p.nbuckets < (1u << 14)) return 0;
+    const uint32_t ch = forced >= 0 ? (uint32_t)forced : REDUCE_SPLIT;
+    if (ch < 2 || (ch & (ch - 1)) != 0 || ch > p.nbuckets) return 0;
+    // the last two launches take the shares and the A level together (k_msm_reduce_final2): whole tree workgroups of
+    // shares, and at most one final half of partial sums, for both fan-ins
+    const uint32_t L = p.nbuckets / ch;
+    return L >= 8u && (L / reduce_split_top(L)) % (2u * REDUCE_THREADS) == 0 && L / TREE_IN_MIN <= REDUCE_THREADS / 2u ? ch : 0u;
+}
+
+// points of a tree's input and of every level above it (a geometric tail; upper bound for both fan-ins)
+static inline uint64_t tree_points(uint64_t groups, uint64_t cnt) {
+    uint64_t total = 0;
     for (;;) {
         total += groups * cnt;
         if (cnt == 1) break;
-        cnt = (cnt + TREE_IN_MIN - 1) / TREE_IN_MIN;     // upper bound for both fan-ins
+        cnt = (cnt + TREE_IN_MIN - 1) / TREE_IN_MIN;
     }
-    return total;
+    return total + groups;      // (a one-point input still gets its output slot)
+}
+// scratch: chunk sums + the intermediate levels of the tree; the split form: T, its chunk sums and tree, A and its tree
+uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
+    if (reduce_bits_for(p)) return (uint64_t)n_msm * p.sets * (p.nbuckets / 128u + 1u) * BITS_RS;      // block records (G2 blocks are the smaller)
+    const uint64_t groups = (uint64_t)n_msm * p.sets;
+    if (const uint32_t ch = reduce_split_for(p)) {
+        const uint64_t L = p.nbuckets / ch;
+        return groups * L + tree_points(groups, L / reduce_split_top((uint32_t)L) + L);      // T; shares and A side by side, the partial sums behind them
+    }
+    return tree_points(groups, p.nbuckets / reduce_chunk_for(p));
 }
 
 // exclusive scan of counts[0..total) -> out[0..total], out[total] = grand total;
@@ -1394,6 +1487,11 @@ uint64_t msm_accum_workspace_slots(uint64_t max_entries) {
     return total;
 }
 
+static bool skip_followups_probe() {      // ZKHIP_PROBE_SKIP_FOLLOWUPS (-DZK_PROBES builds only, WRONG results): no partial merges, no bucket reductions
+    static const bool skip = probe_env("ZKHIP_PROBE_SKIP_FOLLOWUPS") != nullptr;
+    return skip;
+}
+
 template <class F>
 static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_t *entries, AccumBatch batch,
                          uint32_t total_buckets, uint64_t max_entries,
@@ -1412,6 +1510,7 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
                            batch, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes, accum_chunk_min());
     }
     if (ev) ZK_HIP(hipEventRecord(ev[1], s));
+    if (skip_followups_probe()) return;
     if (tail.stream && tail.stream != s) {            // partial merges continue on the caller's follow-up stream
         ZK_HIP(hipEventRecord(tail.l1_done, s));
         ZK_HIP(hipStreamWaitEvent(tail.stream, tail.l1_done, 0));
@@ -1470,6 +1569,7 @@ void launch_msm_accum_g2(G2Acc *buckets, const uint32_t *offsets, const uint32_t
 
 template <class F>
 static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *buckets, uint32_t n_msm, MsmPlan p, hipStream_t s) {
+    if (skip_followups_probe()) return;
     if (reduce_bits_for(p)) {          // c sums per bucket set (msm_wsum_rc), the host finishes
         const uint32_t NE = REDUCE_THREADS / LaneModel<F>::LPE, groups = n_msm * p.sets;
         const uint32_t nblk = p.nbuckets > NE ? p.nbuckets / NE : 1u;
@@ -1479,17 +1579,31 @@ static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *b
         ZK_LAUNCH_OK("msm bucket reduction (bit sums)");
         return;
     }
-    uint32_t chunk = reduce_chunk_for(p);
-    uint32_t cnt = p.nbuckets / chunk;
     const uint32_t groups = n_msm * p.sets;
-    uint32_t total_chunks = groups * cnt;
-    hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks * LaneModel<F>::LPE + 127) / 128), dim3(128), 0, s, scratch, buckets, p.nbuckets, chunk, total_chunks);
     const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename LaneModel<F>::R>);
     const uint32_t TREE_IN = tree_in<F>();
+    auto chunks = [&](ACCMEM *out, uint32_t out_stride, const ACCMEM *in, uint32_t n, uint32_t chunk) {      // sum_k (k+1) in[k] over n points per set -> n / chunk shares
+        const uint32_t total_chunks = groups * (n / chunk);
+        hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks * LaneModel<F>::LPE + 127) / 128), dim3(128), 0, s, out, out_stride, in, n, chunk, total_chunks);
+    };
+    if (const uint32_t ch = reduce_split_for(p)) {
+        const uint32_t L = p.nbuckets / ch, top = reduce_split_top(L), nx = L / top, per = nx + L;      // per set: nx shares, then the L points of the A level
+        ACCMEM *T = scratch, *Y = T + (uint64_t)groups * L, *P = Y + (uint64_t)groups * per;
+        hipLaunchKernelGGL(k_msm_reduce_split<F>, dim3((L * LaneModel<F>::LPE + 127) / 128, groups), dim3(128), 0, s, Y + nx, per, T, buckets, p.nbuckets, ch, L);
+        chunks(Y, per, T, L, top);
+        const uint32_t bx = nx / TREE_IN, ba = L / TREE_IN;        // whole workgroups of each kind (reduce_split_for)
+        hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(bx + ba, groups), dim3(REDUCE_THREADS), lds, s, P, window_sums, (const ACCMEM *)Y, per, 0u);
+        hipLaunchKernelGGL(k_msm_reduce_final2<F>, dim3(groups), dim3(REDUCE_THREADS), lds, s, window_sums, (const ACCMEM *)P, bx, ba, (uint32_t)__builtin_ctz(ch));
+        ZK_LAUNCH_OK("msm bucket reduction (split)");
+        return;
+    }
+    const uint32_t chunk = reduce_chunk_for(p);
+    uint32_t cnt = p.nbuckets / chunk;
+    chunks(scratch, cnt, buckets, p.nbuckets, chunk);
     ACCMEM *in = scratch;
     for (;;) {
-        uint32_t blocks = (cnt + TREE_IN - 1) / TREE_IN;
-        bool last = blocks == 1;
+        const uint32_t blocks = (cnt + TREE_IN - 1) / TREE_IN;
+        const bool last = blocks == 1;
         ACCMEM *out = in + (uint64_t)groups * cnt;
         hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(blocks, groups), dim3(REDUCE_THREADS), lds, s, out, window_sums, (const ACCMEM *)in, cnt, last ? 1u : 0u);
         if (last) break;
