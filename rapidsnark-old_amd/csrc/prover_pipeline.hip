@@ -205,7 +205,7 @@ struct PhaseCtx {
         bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
     }
     void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
-    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; t.buckets_zeroed = q.zeroed; return t; }
+    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; t.buckets_zeroed = q.zeroed; t.chunk_min = q.l1_chunk_min; return t; }
     hipStream_t after(int m, hipStream_t own) const { return tail[m] ? tail[m] : own; }
     NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
 };
@@ -303,6 +303,15 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     // 2^22 synchronous 39.0-39.8 / 37.9-38.0 ms, 2^20 13.3 / 12.4 ms; rank-0 share of 8 shards one at a time 7.8-8.0 / 6.5 ms).
     // (A captured graph keeps whatever its slot recorded.)
     if (!p->capturing) p->slot[si].use_tails = p->in_flight > 0 || p->use_graph;
+    // Entries per level-1 lane.  A LONE proof wants every lane the chip holds (32 entries each at least); a proof submitted beside
+    // others shares the chip anyway, and fewer, longer lanes leave fewer cut runs to merge: with 128 at least the pipelined period
+    // is 2^17 -1.5 %, 2^18 -7 %, 2^19 -2.5 %, 2^20 -1.8 %, 2^22 with a realistic witness -3 ... -4 % (its witness MSMs are sparse), 2^16 +16 % (left out) — and one proof
+    // at a time +0.3 ... 0.4 ms had it been applied there (profiles/r05zk_*, r05zl_*, r05zm_*).
+    if (!p->capturing) {
+        static const uint32_t thr_min = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MIN_BUSY"); return e ? (uint32_t)atoi(e) : 128u; }();
+        static const uint32_t thr_log = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MIN_BUSY_LOG"); return e ? (uint32_t)atoi(e) : 17u; }();
+        p->slot[si].l1_chunk_min = (p->in_flight > 0 && !p->use_graph && p->shard_count == 1 && !p->part && p->batch == 1 && p->logn >= thr_log) ? thr_min : 0u;
+    }
     PhaseCtx c(p, si);
     zk_prover::ProofSlot &q = c.q;
     bool staged = h_wtns != nullptr;
