@@ -160,6 +160,7 @@ struct AccumTail {
     hipEvent_t l1_done = nullptr;
     bool buckets_zeroed = false;      // the caller has already cleared the bucket array (ordered before this launch)
     uint32_t chunk_min = 0;           // entries per level-1 lane at least (0: ACC_CHUNK_MIN); more = fewer lanes, fewer partial sums to merge
+    uint32_t chunk_max = 0;           // entries per lane beyond which another round of lanes is launched (0: ACC_CHUNK_MAX)
 };
 // Up to three G1 MSMs over the SAME sorted entry list in one set of launches (blockIdx.y): MSM m uses
 // points[m], writes buckets + m*bucket_stride and the workspaces + m*ws_stride.

@@ -1465,9 +1465,9 @@ static uint64_t accum_round_lanes(uint32_t n_msm) {
     return lanes ? lanes : 1;
 }
 template <class F>
-static inline uint64_t accum_lanes_for(uint64_t max_entries, uint32_t n_msm, uint32_t chunk_min = 0) {
+static inline uint64_t accum_lanes_for(uint64_t max_entries, uint32_t n_msm, uint32_t chunk_min = 0, uint32_t chunk_max = 0) {
     if (!max_entries) max_entries = 1;
-    const uint64_t R = accum_round_lanes<F>(n_msm), cmin = chunk_min ? chunk_min : accum_chunk_min(), cmax = accum_chunk_max();
+    const uint64_t R = accum_round_lanes<F>(n_msm), cmin = chunk_min ? chunk_min : accum_chunk_min(), cmax = chunk_max ? chunk_max : accum_chunk_max();
     if (max_entries <= R * cmin) return (max_entries + cmin - 1) / cmin;       // one partial round of minimum chunks
     const uint64_t rounds = (max_entries + R * cmax - 1) / (R * cmax);
     return rounds * R;
@@ -1500,7 +1500,7 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
     // empty buckets are never written by the kernels: infinity is the all-zero pattern
     if (!tail.buckets_zeroed) ZK_HIP(hipMemsetAsync(buckets, 0, ((size_t)(nb - 1) * batch.bucket_stride + total_buckets) * sizeof(ACCMEM), s));
     const uint32_t cmin = tail.chunk_min > accum_chunk_min() ? tail.chunk_min : accum_chunk_min();      // (never more lanes than the workspace was sized for)
-    uint64_t lanes = accum_lanes_for<F>(max_entries, nb, cmin);
+    uint64_t lanes = accum_lanes_for<F>(max_entries, nb, cmin, tail.chunk_max > accum_chunk_max() ? tail.chunk_max : 0u);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
         hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK)), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,

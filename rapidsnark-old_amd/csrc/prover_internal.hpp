@@ -210,7 +210,7 @@ struct zk_prover {
     struct ProofSlot {
         bool allocated = false, busy = false;
         bool use_tails = true;                // this proof's merges / reductions on the follow-up streams (decided at submit)
-        uint32_t l1_chunk_min = 0;            // entries per level-1 lane at least (0: msm.hip's default), decided at submit
+        uint32_t l1_chunk_min = 0, l1_chunk_max = 0;      // entries per level-1 lane: at least / per round at most (0: msm.hip's defaults), decided at submit
         SortBufs sort_w;
         DevBuf<G1Acc> buckets_g1;    // A | B1 | C | H   (A,B1,C use sort_w's plan; H uses sort_h's)
         DevBuf<G2Acc> buckets_g2;

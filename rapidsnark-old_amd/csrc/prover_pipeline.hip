@@ -205,7 +205,7 @@ struct PhaseCtx {
         bA = q.buckets_g1.p; bB1 = bA + tbw; bC = bB1 + tbw; bH = bC + tbw;
     }
     void mark(int i) const { if (tm) HIP_TRY(hipEventRecord(q.ev[i], s)); }
-    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; t.buckets_zeroed = q.zeroed; t.chunk_min = q.l1_chunk_min; return t; }
+    AccumTail tail_of(int m) const { AccumTail t; t.stream = tail[m]; t.l1_done = q.ev_l1[m]; t.buckets_zeroed = q.zeroed; t.chunk_min = q.l1_chunk_min; t.chunk_max = q.l1_chunk_max; return t; }
     hipStream_t after(int m, hipStream_t own) const { return tail[m] ? tail[m] : own; }
     NttTables tables() const { return NttTables{p->logn, p->tw_fwd.p, p->tw_inv.p, p->tw_coset.p, p->tw_ninv.p}; }
 };
@@ -310,7 +310,11 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     if (!p->capturing) {
         static const uint32_t thr_min = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MIN_BUSY"); return e ? (uint32_t)atoi(e) : 128u; }();
         static const uint32_t thr_log = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MIN_BUSY_LOG"); return e ? (uint32_t)atoi(e) : 17u; }();
-        p->slot[si].l1_chunk_min = (p->in_flight > 0 && !p->use_graph && p->shard_count == 1 && !p->part && p->batch == 1 && p->logn >= thr_log) ? thr_min : 0u;
+        static const uint32_t thr_max = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MAX_BUSY"); return e ? (uint32_t)atoi(e) : 1280u; }();
+        const bool busy = p->in_flight > 0 && !p->use_graph && p->shard_count == 1 && !p->part && p->batch == 1 && p->logn >= thr_log;
+        p->slot[si].l1_chunk_min = busy ? thr_min : 0u;
+        p->slot[si].l1_chunk_max = busy ? thr_max : 0u;      // fewer rounds of lanes: at 2^22 H runs as one round of 277 entries per lane, A|B1|C as one of 832
+                                                             // (160 / 320 / 640 / 1280 / one round always: 2^22 30.65 / 30.59 / 30.29 / 30.07 / 30.08 ms, 2^24 121.4 / 118.8 / 116.4 / 116.1 / 118.4; profiles/r05zn_*, r05zo_*)
     }
     PhaseCtx c(p, si);
     zk_prover::ProofSlot &q = c.q;
