@@ -226,7 +226,9 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
         // time 13.9 -> 12.7.  Only 2^20 and 2^21 unsharded measured neutral on the period and 0.3-0.5 ms WORSE for a lone proof
         // (three level-1 launches of 1-2 ms interleave with the other stream's work, one of 3-6 ms does not): off there.
         const char *e = getenv("ZKHIP_BATCH_ABC");
-        const bool mid_size_unsharded = p->shard_count == 1 && p->sv.size() >= (1u << 20) && p->sv.size() < (1u << 22);
+        // Round 5 (busy proofs run fewer, longer lanes; c = 20 at 2^21): 2^21 now gains 1.8 % on the period with a lone proof equal
+        // (profiles/r05zp_batch_abc_mid_sizes.txt, three alternations), 2^20 is still neutral: off at 2^20 only.
+        const bool mid_size_unsharded = p->shard_count == 1 && p->sv.size() >= (1u << 20) && p->sv.size() < (1u << 21);
         p->batch_abc = e ? atoi(e) != 0 : !mid_size_unsharded;
     }
     HIP_TRY(hipEventCreateWithFlags(&p->ev_ext_in, hipEventDisableTiming));
