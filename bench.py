@@ -548,7 +548,7 @@ def summary_of(out):
 
 def counters_child(args):
     """The process rocprofv3 --pmc wraps (rapidsnark_old_amd.counters.run_pass): for every leg, a prover of that configuration,
-    a begin marker, one warm-up + `--counters-proofs` synchronous proofs with the witness resident, an end marker."""
+    a begin marker, 1 + `--counters-proofs` proofs with the witness resident, each submitted beside one more in flight, an end marker."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import rapidsnark_old_amd as zk
@@ -563,10 +563,15 @@ def counters_child(args):
                            sparse_witness=realistic and bool(args.precomp))
         w = torch.from_numpy(synth.make_witness(k, seed=1, kind="realistic" if realistic else "uniform", n_vars=wl["nVars"])).cuda()
         torch.cuda.synchronize()
+        # the proofs between the markers are submitted while another one is in flight (uncollected), like every proof of the
+        # timed legs but the first: the library gives such a proof fewer, longer level-1 lanes (fewer partial sums to merge)
+        p.submit_dev(w.data_ptr())
         marker(zk, torch, counters.MARK_BEGIN + i)
         for _ in range(1 + args.counters_proofs):
-            p.prove_dev(w.data_ptr())
+            p.submit_dev(w.data_ptr())
+            p.collect()
         marker(zk, torch, counters.MARK_END + i)
+        p.collect()
         p.lib.zk_prover_destroy(p.h)
         del w, wl
     print("[counters-child] done", flush=True)

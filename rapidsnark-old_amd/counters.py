@@ -2,7 +2,7 @@
 (SQ_INSTS_VALU) of the proof path's kernels.
 
 Two sources, in this order:
-  measure()  — rocprofv3 --pmc around a CHILD process (`bench.py --counters-child <legs>`: a few synchronous proofs per leg,
+  measure()  — rocprofv3 --pmc around a CHILD process (`bench.py --counters-child <legs>`: a few proofs per leg, each beside one more in flight,
                legs separated by marker launches), run by the bench itself after its timed legs: the figures of the line are
                then observed on the box that printed the line.  FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots:
                MI355X_MICROARCH.md, "rocprofv3 PMC slots"); SQ_INSTS_VALU (another block) rides with the first.
@@ -139,7 +139,7 @@ def measure(legs, bench_py, precomp=1, proofs=2, log=None):
     for leg, s in out.items():
         if "valu_instructions_per_proof" not in s or "g1_hbm_bytes_per_msm" not in s:
             raise RuntimeError("counter passes hold no kernels of leg %s" % leg)
-    return out, "measured in this run (rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU / --pmc WRITE_SIZE around %d synchronous proofs per leg)" % proofs
+    return out, "measured in this run (rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU / --pmc WRITE_SIZE around %d proofs per leg, each submitted beside one more in flight)" % proofs
 
 
 # ---------------------------------------------------------------- replay of the committed passes (fallback)
