@@ -311,7 +311,12 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
         static const uint32_t thr_min = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MIN_BUSY"); return e ? (uint32_t)atoi(e) : 128u; }();
         static const uint32_t thr_log = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MIN_BUSY_LOG"); return e ? (uint32_t)atoi(e) : 17u; }();
         static const uint32_t thr_max = [] { const char *e = probe_env("ZKHIP_L1_CHUNK_MAX_BUSY"); return e ? (uint32_t)atoi(e) : 1280u; }();
-        const bool busy = p->in_flight > 0 && !p->use_graph && p->shard_count == 1 && !p->part && p->batch == 1 && p->logn >= thr_log;
+        // the shards of a sharded proof too, by the size of a shard: rank-0 share of eight shards of 2^22 with two in flight 5.42 -> 5.00 ms,
+        // of 2^24 16.65 -> 16.30, two shards 16.6 -> 16.3, four equal (profiles/r05zt_busy_lanes_shards.txt; ZKHIP_L1_BUSY_SHARDS=0: probe)
+        static const bool shards_too = [] { const char *e = probe_env("ZKHIP_L1_BUSY_SHARDS"); return e ? atoi(e) != 0 : true; }();
+        uint32_t lg_sh = 0;
+        while ((1u << (lg_sh + 1)) <= p->shard_count) lg_sh++;
+        const bool busy = p->in_flight > 0 && !p->use_graph && ((p->shard_count == 1 && !p->part) || shards_too) && p->batch == 1 && p->logn >= thr_log + lg_sh;
         p->slot[si].l1_chunk_min = busy ? thr_min : 0u;
         p->slot[si].l1_chunk_max = busy ? thr_max : 0u;      // fewer rounds of lanes: at 2^22 H runs as one round of 277 entries per lane, A|B1|C as one of 832
                                                              // (160 / 320 / 640 / 1280 / one round always: 2^22 30.65 / 30.59 / 30.29 / 30.07 / 30.08 ms, 2^24 121.4 / 118.8 / 116.4 / 116.1 / 118.4; profiles/r05zn_*, r05zo_*)
