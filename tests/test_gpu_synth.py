@@ -290,3 +290,38 @@ def test_sparse_witness_flag_changes_the_window_not_the_sums(zk):
     assert sums[(True, "realistic")] == sums[(False, "realistic")] and sums[(True, "uniform")] == sums[(False, "uniform")]
     assert sums[(True, "realistic")] != sums[(True, "uniform")]
     assert used[1] > used[0] * 1.02, used          # 16 rows per point for A, B1, B2, C instead of 14 (the bucket arrays shrink: +3.6 % in all)
+
+
+@pytest.mark.parametrize("precomp", [False, True])
+def test_proofs_submitted_beside_others_bit_exact_vs_c_oracle(zk, precomp):
+    """From 2^17 a proof submitted while another one is in flight runs fewer, longer level-1 lanes (at least 128 entries each, one
+    round of lanes up to 1280: csrc/prover_pipeline.hip, "entries per level-1 lane") — another cut of the bucket runs, the same sums.
+    Three proofs in flight on an unsharded prover and on shard 1 of 2 (the rule goes by the shard's size), against the C
+    restatement of src/groth16.cpp:171-204 and, assembled with shard 0's share, of the whole prove()."""
+    import torch
+    from rapidsnark_old_amd import synth
+    k = 18                                                              # (a shard of two is 2^17: the smallest the rule takes)
+    wl = _gpu_workload(zk, k)
+    view = co.ZkeyView(wl)
+    ws = [synth.make_witness(k, seed=s) for s in (1, 2, 3)]
+    wd = [torch.from_numpy(w).to("cuda:0") for w in ws]
+    want = [co.prove_msm(view, w) for w in ws]
+    p = _prover(zk, wl, precomp=precomp)
+    assert p.info()["window_bits_h"] == (16 if precomp else 12)           # (the plan of a 2^18 vector: 2^15 / 2^11 buckets)
+    assert p.prove_msm_dev(wd[0].data_ptr()) == want[0]                 # a lone proof: the latency plan
+    for d in wd:
+        p.submit_dev(d.data_ptr())
+    assert [p.collect_msm() for _ in wd] == want                        # the second and third: the busy plan
+    import ctypes as C
+    p.lib.zk_prover_destroy(p.h)
+    p.h = C.c_void_p()
+    shard = [_prover(zk, wl, precomp=precomp, shard_index=i, shard_count=2) for i in range(2)]
+    lone = [[q.prove_msm_dev(d.data_ptr()) for d in wd] for q in shard]
+    for d in wd:
+        shard[1].submit_dev(d.data_ptr())
+    busy = [shard[1].collect_msm() for _ in wd]
+    assert busy == lone[1]
+    r, s = 0x1234567, (1 << 200) + 99
+    vk = {name: np.asarray(wl[name]).tobytes() for name in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2")}
+    for i, w in enumerate(ws):
+        assert zk.assemble(vk, [lone[0][i], busy[i]], r, s) == co.prove(view, w, r, s)
