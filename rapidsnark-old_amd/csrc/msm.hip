@@ -647,7 +647,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_bin_scatter_staged(uint32_t *ent
 // 768 workgroups, G2: 2 waves/SIMD = 512), and a last round that is only partly full costs a whole round:
 // at 2^22 a fixed chunk of 128 gave 1664 workgroups = 2.17 rounds, i.e. the kernel ran at 72% of its own
 // rate.  So the host launches a WHOLE number of rounds of lanes (accum_lanes_for) and the chunk is whatever
-// divides the entries evenly among them (32..160 entries; below 32 fewer lanes are launched instead).
+// divides the entries evenly among them (32..160 entries; below 32 fewer lanes are launched instead).  That is a LONE proof's
+// plan; one submitted beside others takes 128..1280 entries per lane (AccumTail::chunk_min / chunk_max, set in prover_pipeline.hip):
+// the chip is shared anyway, and fewer lanes leave fewer cut runs to merge.
 #define ACC_CHUNK_MAX 160u  // affine points per lane, level 1: more than this and another round of lanes is launched
 #define ACC_CHUNK_MIN 32u   // fewer than this and fewer lanes are launched (small or sharded MSMs)
 // Every lane takes the same share of the E entries actually present (E <= max_entries is known on the device
