@@ -440,7 +440,10 @@ void phase_local(zk_prover *p) {
     const bool a2a = p->part && !p->have_peers;          // blocks travel through the caller's all_to_all
     if (a2a) launch_chunk_unpack(c.abc, p->pk_use, 3, p->logn, p->log_shards, c.s);
     if (p->pair.L) {
-        launch_ntt_coset_pair(c.abc, nl, 3 * c.q.count, p->pair, c.s);      // inverse, coset shift * 1/n, forward: nttpair.hip
+        // ZKHIP_PROBE_SKIP_NTT (-DZK_PROBES builds only, WRONG results): only a is transformed, b and c are not — two thirds of the
+        // transforms made free (h stays a dense vector of full-size scalars; with none transformed a.b - c would be 0)
+        static const bool skip_ntt = probe_env("ZKHIP_PROBE_SKIP_NTT") != nullptr;
+        launch_ntt_coset_pair(c.abc, nl, (skip_ntt ? 1 : 3) * c.q.count, p->pair, c.s);      // inverse, coset shift * 1/n, forward: nttpair.hip
     } else {
         launch_ntt_dif_inverse(c.abc, nl, 3 * c.q.count, tb, c.s, local_logn);
         launch_ntt_dit_forward(c.abc, nl, 3 * c.q.count, tb, c.s, p->tw_coset.p + (p->part ? p->sh.lo : 0), local_logn);   // coset shift * 1/n fused into the first pass
