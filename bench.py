@@ -141,7 +141,7 @@ def main():
 def run(args):
     if args.batch > 1 and (args.steps % args.batch or args.gpus != 1):
         raise SystemExit("--batch B needs --gpus 1 and --steps a multiple of B")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # six streams per prover (csrc/prover.hip); read when HIP initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # six streams per prover (csrc/prover_create.hip); read when HIP initialises
     import torch
     import rapidsnark_old_amd as zk
     from rapidsnark_old_amd import synth

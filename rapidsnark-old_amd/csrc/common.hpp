@@ -1,5 +1,5 @@
 // Shared host-side plumbing of libzkhip: error reporting across the C ABI and the
-// host-tail entry points (compiled by g++ in host_tail.cpp, called from prover.hip).
+// host-tail entry points (compiled by g++ in host_tail.cpp, called from prover_pipeline.hip).
 #pragma once
 #include <stdint.h>
 #include <stddef.h>

@@ -79,6 +79,18 @@ __device__ __forceinline__ int64_t zk_mad_s(int64_t acc, int32_t a, int32_t s) {
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "s"(s));
     return acc;
 }
+#elif defined(ZK_CHECK_COLUMNS) && !defined(__HIP_DEVICE_COMPILE__)
+// host-only checking build (tools/field29_bounds_test.cpp): every MAD in 128 bits, overflows of the 64-bit column counted
+inline long &zk_column_overflows() { static long n = 0; return n; }
+inline __int128 &zk_column_peak() { static __int128 v = 0; return v; }
+inline int64_t zk_mad(int64_t acc, int32_t a, int32_t b) {
+    const __int128 v = (__int128)acc + (__int128)a * b, m = v < 0 ? -v : v;
+    if (m > zk_column_peak()) zk_column_peak() = m;
+    if (v > (__int128)INT64_MAX || v < (__int128)INT64_MIN) zk_column_overflows()++;
+    return (int64_t)v;
+}
+inline int64_t zk_mad0(int32_t a, int32_t b) { return zk_mad(0, a, b); }
+inline int64_t zk_mad_s(int64_t acc, int32_t a, int32_t s) { return zk_mad(acc, a, s); }
 #else
 ZK_HD int64_t zk_mad(int64_t acc, int32_t a, int32_t b) { return acc + (int64_t)a * b; }
 ZK_HD int64_t zk_mad0(int32_t a, int32_t b) { return (int64_t)a * b; }
@@ -199,9 +211,13 @@ struct Fp29 {
     }
 
     // ---- Montgomery products a*b*2^-261 (mod p), product-scanning over 17 columns of v_mad_i64_i32.
-    // A column is a CHAIN of MADs into one 64-bit accumulator (|column| < 27 * 2^58 < 2^63 even for the fused
-    // double product); the carry of column k (acc >> 29) is the addend of column k+1's first MAD, so there is no
-    // 64-bit add per column.  A "job" lists the operand products of a column; the engine below runs
+    // A column is a CHAIN of MADs into one 64-bit accumulator; the carry of column k (acc >> 29) is the addend of column
+    // k+1's first MAD, so there is no 64-bit add per column.  Budget of a column (2^63 = 32 * 2^58): the reduction terms take
+    // 2^31 * (sum of the modulus limbs) = 12.05 * 2^58 (Fq) / 13.6 * 2^58 (Fr) now that the lower eight reduction digits are
+    // unmasked (mont_m), so the OPERAND terms of a job must stay within 18 * 2^58 of one sign — 18 products of tight limbs, or
+    // 9 of tight x wide (one lazily added operand), see the job shapes below; Fr with a lazily added operand has ~1 % left.
+    // tools/field29_bounds_test.cpp (-DZK_CHECK_COLUMNS: every MAD checked in 128 bits) runs each job shape the kernels use
+    // over extreme and random operands of the callers' limb ranges.  A "job" lists the operand products of a column; the engine below runs
     //   run2: TWO independent jobs with their chains interleaved MAD by MAD — the dependent-issue latency of one
     //         chain is covered by the other (what hipcc's split-and-merge bought, without its 17 merge adds), and no
     //         result is consumed by the very next instruction (hipcc puts an s_nop behind an inline asm whose
@@ -284,7 +300,8 @@ struct Fp29 {
     struct JMulAdd4 {                   // a * b + c * d + e * f + g * h with ONE reduction (the G2 lane pair's Y3 = R*D - Y1*PPP)
         // Column bound: 36 operand terms.  Callers keep every limb non-negative up to the carry slack ([-8, 2^29 + 8]) and
         // arrange the signs so that two of the four products enter negated: at most 18 terms of one sign (18 * 2^58) plus the
-        // reduction terms (sum of the modulus limbs ~ 3.01 * 2^29, i.e. < 3.1 * 2^58) stay below 2^63.
+        // reduction terms (2^31 * sum of the modulus limbs = 12.05 * 2^58 for Fq, the only field this job runs in) stay below
+        // 2^63 = 32 * 2^58.
         const Fp29 &a, &b, &c, &d, &e, &f, &g, &h;
         ZK_HD static constexpr int n(int k) { return 4 * col_n(k); }
         ZK_HD void term(int64_t &acc, int k, int t, bool first) const {

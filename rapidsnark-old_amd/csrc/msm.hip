@@ -568,6 +568,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *offsets, cons
 #ifndef STAGE_CAP
 #define STAGE_CAP 8192u
 #endif
+// The kernel's LDS layout (2048 bucket counters as two words per thread: loc[tid], loc[tid + SCAN_BLOCK]; a 16-entry area of
+// wave totals; PER = STAGE_CAP / SCAN_BLOCK entries per thread; positions in a tile as u16) is written for exactly these values:
+static_assert(SCAN_BLOCK == 1024u && STAGE_CAP % SCAN_BLOCK == 0 && STAGE_CAP <= 65536u, "k_bin_scatter_staged: retune its LDS layout with SCAN_BLOCK / STAGE_CAP");
 __global__ __launch_bounds__(SCAN_BLOCK) void k_bin_scatter_staged(uint32_t *entries, const uint32_t *starts, const uint16_t *lo, const uint32_t *val,
                                                                    const uint32_t *bin_starts, uint32_t nblocks, uint32_t buckets_per_bin, uint32_t nbins,
                                                                    uint32_t slices, uint32_t total_buckets) {
@@ -676,9 +679,8 @@ __device__ __forceinline__ uint32_t accum_chunk_dev(uint32_t E, uint32_t nlanes,
 #define FLAG_STARTS 1u
 #define FLAG_ENDS 2u
 
-// Occupancy is what the compiler picks: G1 132 VGPRs (3 waves/SIMD), G2 256 + 53 AGPRs (1 wave/SIMD).
-// Forcing 4 G1 waves (128 VGPRs, 20 B scratch) or 2 G2 waves (256 VGPRs, 256 B scratch) was measured
-// slower for the whole proof.
+// Occupancy is what the compiler picks: G1 132 VGPRs (3 waves/SIMD); the G2 kernel (Fq2 split over lane pairs, below) 212 VGPRs
+// (2 waves/SIMD).  Forcing 4 G1 waves (128 VGPRs, 20 B scratch) was measured slower for the whole proof.
 // blockIdx.y selects one of up to three MSMs over the SAME sorted entry list (A, B1, C share sort(w)):
 // small circuits launch them together — a level-1 launch there is latency-bound (a lane's chain of 32
 // adds, a grid that does not fill the chip) and three of them cost what one costs.

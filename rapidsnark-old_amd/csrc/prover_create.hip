@@ -427,6 +427,24 @@ int zk_prover_reserve(zk_prover *p, uint32_t in_flight, uint32_t host_witnesses)
         if (p->in_flight || p->phase_open >= 0) throw std::invalid_argument("proofs in flight");
         p->ring = nslots == 1 ? ZK_MAX_IN_FLIGHT : (uint32_t)nslots;
         p->next_submit = p->next_collect = 0;
+        // What an earlier, deeper reservation that ran out of memory left behind (slots and lanes beyond this ring) goes back
+        // first: the retry with a shallower pipeline (Groth16::makeProver's fallback chain) must see the memory a fresh
+        // prover would see.  Nothing is in flight (checked above), so nothing is using them.
+        HIP_TRY(hipDeviceSynchronize());
+        for (int i = nslots; i < (int)ZK_MAX_IN_FLIGHT; i++)
+            p->slot[i].release_memory();
+        for (int lane = nslots < 1 ? 1 : nslots; lane < p->lanes; lane++)
+            if (p->extra[lane - 1]) p->extra[lane - 1]->release_memory();
+        // Every slot of the ring is allocated NOW (device workspace, and for host witnesses the HBM witness buffer and its
+        // pinned staging copy), so that out-of-memory is a start-up error and the first `depth` proofs do not pay for it.
+        for (int i = 0; i < nslots; i++) {
+            alloc_slot(p, i);
+            if (host_witnesses) {
+                zk_prover::ProofSlot &q = p->slot[i];
+                ensure_witness_buffer(p, q);
+                if (!q.wtns_pin) HIP_TRY(hipHostMalloc((void **)&q.wtns_pin, (size_t)p->nVars * 32 * p->batch, hipHostMallocDefault));
+            }
+        }
         for (int lane = 1; lane < p->lanes && lane < nslots; lane++) p->extra[lane - 1]->ensure();
     });
 }

@@ -152,6 +152,11 @@ struct SortBufs {
         bin_counts.alloc(z.bin_counts_u32);
         bin_starts.alloc(z.bin_starts_u32);
     }
+    void release() {
+        lo.release(); counts.release(); starts.release(); offsets.release(); entries.release();
+        codes.release(); val.release(); bin_counts.release(); bin_starts.release();
+        n = 0; ran = false;
+    }
     bool ran = false;
     void run(const Fr *scalars, hipStream_t s) {
         // ZKHIP_PROBE_SKIP_SORT=1 (-DZK_PROBES builds only; wrong sums): the sort runs once per buffer set and its result is reused —
@@ -253,6 +258,22 @@ struct zk_prover {
         const Fr *graph_wtns = nullptr;
         hipEvent_t ev_gdone = nullptr;      // recorded behind the graph launch: what a collect waits for
         bool via_graph = false;
+        // Give the slot's device and pinned memory back (events stay).  Only for a slot no proof is using: zk_prover_reserve
+        // does this to the slots beyond a ring that a failed, deeper reservation left allocated.
+        void release_memory() {
+            allocated = false;
+            sort_w.release();
+            buckets_g1.release(); buckets_g2.release(); scratch_g1.release(); acc_ws_g1_all.release();
+            acc_key_all.release(); acc_flag_all.release(); scratch_g2.release(); acc_ws_g2.release();
+            wsum_g1.release(); wsum_g2.release(); wtns_dev.release();
+            if (w1) { (void)hipHostFree(w1); w1 = nullptr; }
+            if (w2) { (void)hipHostFree(w2); w2 = nullptr; }
+            if (wtns_pin) { (void)hipHostFree(wtns_pin); wtns_pin = nullptr; }
+            if (pin_ring) { (void)hipHostFree(pin_ring); pin_ring = nullptr; }
+            if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+            if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+            graph_wtns = nullptr;
+        }
         ~ProofSlot() {
             if (gexec) (void)hipGraphExecDestroy(gexec);
             if (graph) (void)hipGraphDestroy(graph);
@@ -304,6 +325,10 @@ struct zk_prover {
             if (!h.p) h.alloc(n_h);
             sort_h.alloc(nh_sort, wbits, precomp, batch);      // (releases what an interrupted call left, then allocates all nine buffers)
             ready = true;
+        }
+        void release_memory() {      // buffers only: the streams (hardware queues) are cheap to keep and slow to make
+            ready = false;
+            abc.release(); h.release(); sort_h.release();
         }
         ~LaneExtra() {
             if (stream2 && stream2 != stream) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }

@@ -83,7 +83,7 @@ def load_library():
         raise ZkHipError("libzkhip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C rapidsnark-old_amd/csrc`; there is no CPU fallback" % path)
     # six streams per prover: the HIP runtime's default of 4 hardware queues aliases them and the
-    # witness upload of proof k+1 then queues behind proof k (csrc/prover.hip); read at HIP init
+    # witness upload of proof k+1 then queues behind proof k (csrc/prover_create.hip); read at HIP init
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     try:
         # torch wheels bundle their own libamdhip64; load it FIRST so this process holds ONE HIP

@@ -4,7 +4,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # read when HIP initialises (rapidsnark-old_amd/csrc/prover.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # read when HIP initialises (rapidsnark-old_amd/csrc/prover_create.hip)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

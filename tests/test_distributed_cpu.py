@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _shard_view(zk_bytes, wt_vals, idx, cnt):
-    """Slice every table like csrc/prover.hip::prover_create does (contiguous index ranges)."""
+    """Slice every table like csrc/prover_create.hip::prover_create does (contiguous index ranges)."""
     from oracle import c_oracle as co
     full = co.ZkeyView(zk_bytes)
     v = full.v

@@ -325,3 +325,32 @@ def test_proofs_submitted_beside_others_bit_exact_vs_c_oracle(zk, precomp):
     vk = {name: np.asarray(wl[name]).tobytes() for name in ("vk_alpha1", "vk_beta1", "vk_beta2", "vk_delta1", "vk_delta2")}
     for i, w in enumerate(ws):
         assert zk.assemble(vk, [lone[0][i], busy[i]], r, s) == co.prove(view, w, r, s)
+
+
+def test_reserve_allocates_every_slot_of_the_ring_at_start_up(zk):
+    """zk_prover_reserve (include/zkhip.h): the workspace of every slot and lane a pipeline of the reserved depth walks exists
+    when the call returns — out of memory is a start-up error (Groth16::makeProver's fallback chain depends on it) and the first
+    proofs do not pay for allocations.  Device memory in use must grow at reserve and NOT move while the pipeline fills; a
+    shallower reservation afterwards gives the slots beyond its ring back."""
+    from rapidsnark_old_amd import synth
+    k = 16
+    wl = _gpu_workload(zk, k)
+    w = synth.make_witness(k, seed=5)
+    p = _prover(zk, wl, precomp=True)
+    before = p.info()["device_bytes_in_use"]
+    depth = 4
+    p.reserve(depth)
+    reserved = p.info()["device_bytes_in_use"]
+    assert reserved - before > (depth - 1) * 8 * (1 << 20), "reserve allocated nothing"
+    r, s = 12345, 67890
+    for _ in range(depth):
+        p.submit_host(w, r, s)
+    full = p.info()["device_bytes_in_use"]
+    assert full == reserved, "slots were allocated at submit: %d bytes" % (full - reserved)
+    proofs = [p.collect() for _ in range(depth)]
+    assert len(set(proofs)) == 1 and proofs[0] == p.prove_host(w, r, s)
+    p.reserve(2)
+    assert p.info()["device_bytes_in_use"] < reserved, "slots beyond the shallower ring were kept"
+    for _ in range(2):
+        p.submit_host(w, r, s)
+    assert [p.collect() for _ in range(2)] == proofs[:2]

@@ -239,3 +239,15 @@ def test_column_bounds_of_the_29_bit_limb_products():
         assert reduction + 18 * tight * tight + (1 << 35) < 1 << 63           # a*b + c*d (and the four-product job: <= 18 terms of one sign)
         assert reduction + 9 * tight * wide + (1 << 35) < 1 << 63             # a*b with ONE lazily added operand (DIT butterflies)
         assert reduction + (4 * wide * tight + tight * tight) + (1 << 35) < 1 << 63      # a^2 with the doubled operand
+
+
+def test_no_product_column_leaves_int64_for_the_job_shapes_in_use(tmp_path):
+    """Companion of the analytic bound above: tools/field29_bounds_test.cpp builds field29.hpp / curve29.hpp for the host with every
+    multiply-accumulate evaluated in 128 bits (-DZK_CHECK_COLUMNS) and runs each job shape the kernels use (a*b, a*wide, a^2,
+    a*b + c*d, the four-product job, chains of G1 / G2 mixed additions) over extreme and random operands of the callers' limb ranges."""
+    import subprocess
+    exe = str(tmp_path / "field29_bounds_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DZK_CHECK_COLUMNS", "-I", os.path.join(ROOT, "rapidsnark-old_amd", "csrc"),
+                           os.path.join(ROOT, "tools", "field29_bounds_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK: no column left int64" in out.stdout, out.stdout + out.stderr
