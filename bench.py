@@ -18,6 +18,11 @@ ONE JSON line on rank 0.  Besides the contract's keys:
                 or are replayed from profiles/ when it cannot: `traffic_source` says which.
   cpu_baseline  the C restatement of rapidsnark's CPU algorithm (oracle/) timed on this box's host cores, generic and ADX builds.
   also_2p20, also_realistic, (also_server)   the other configurations of BASELINE's metric, timed by the same code.
+  also_2p24     configs[3]'s size on ONE GPU (pipelined period, synchronous latency), same code.
+  also_shard8   for 2^22 and 2^24: ONE rank's share of a proof split across eight GPUs (MSM tables sharded by point range, chain
+                partitioned), measured on this GPU with the four all_to_all rounds left out; beside it the ideal eighth of this
+                run's single-GPU period and the speed-up the share implies.  No number from eight physical GPUs: the driver
+                owns those runs (SCALE_rNN.json).
   summary       LAST in the line: every scalar DESIGN.md quotes, so that a record keeping only the tail of stdout holds them.
 Definitions of every field: DESIGN.md section 6.
 """
@@ -74,6 +79,8 @@ def parse():
     ap.add_argument("--no-2p20", action="store_true", help="skip the also_2p20 leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--cpu-budget-s", type=float, default=36.0)
     ap.add_argument("--no-counters", action="store_true", help="do not run the rocprofv3 counter passes after the timed legs (replay profiles/ instead)")
+    ap.add_argument("--no-2p24", action="store_true", help="skip the also_2p24 leg of a default run (configs[3]'s size on one GPU, and its rank share of eight)")
+    ap.add_argument("--no-shard8", action="store_true", help="skip the also_shard8 probes of a default run (one rank's share of a proof split across eight GPUs)")
     ap.add_argument("--no-server", action="store_true", help="skip the also_server leg of a default run (proverServer over REST on a Semaphore-class key)")
     ap.add_argument("--counters-child", default="", help=argparse.SUPPRESS)      # internal: the process rocprofv3 wraps (rapidsnark_old_amd.counters)
     ap.add_argument("--counters-proofs", type=int, default=2, help=argparse.SUPPRESS)
@@ -94,6 +101,9 @@ def main():
     default_run = args.gpus == 1 and args.log2n == 22 and not args.no_cpu and args.batch <= 1 and args.witness == "uniform" and args.shape == "dense"
     legs = {LEG_OF.get((args.shape, args.log2n), "headline"): out}
     import copy
+    shard8 = []
+    if "shard8" in out:
+        shard8.append(out.pop("shard8"))
     if default_run and not args.no_realistic:
         # what a REAL circom key and witness look like to the prover (BASELINE configs[4]'s fidelity; SURVEY section 8d's
         # secondary line): the circuit-shaped member of the family with the 80/15/5 witness, timed the same way by the same code
@@ -105,6 +115,24 @@ def main():
         a2 = copy.copy(args)
         a2.log2n, a2.no_cpu, a2.in_flight = 20, True, 0
         legs["2p20"] = run(a2)
+    also_2p24 = None
+    if default_run and not args.no_2p24:
+        # BASELINE configs[3]'s size on ONE GPU (it is "sharded across 8" there: the driver owns that run), and — on the same
+        # workload, before it is released — one rank's share of eight
+        a4 = copy.copy(args)
+        a4.log2n, a4.no_cpu, a4.in_flight = 24, True, 0
+        a4.steps, a4.warmup = min(args.steps, 8), min(args.warmup, 2)
+        try:
+            o4 = run(a4)
+            if "shard8" in o4:
+                shard8.append(o4.pop("shard8"))
+            also_2p24 = {kk: o4[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "resident_witness",
+                                               "latency_ms_one_at_a_time", "stage_ms", "setup_s") if kk in o4}
+            r4 = o4["roofline"]
+            also_2p24["roofline"] = {kk: r4[kk] for kk in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms", "algorithmic_bytes", "launch_ms_one_in_flight",
+                                                          "frac_one_in_flight", "g2_launch_ms", "g2_launch_ms_one_in_flight", "whole_proof_frac", "clock_ghz") if kk in r4}
+        except Exception as exc:           # noqa: BLE001  (a failed extra leg must not cost the line)
+            also_2p24 = {"value": None, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     # ---- counters: measured by this run where rocprofv3 can wrap a child of it, else replayed from profiles/
     from rapidsnark_old_amd import counters
     measured, how = {}, None
@@ -132,6 +160,10 @@ def main():
             o = legs[leg]
             out[key] = {kk: o[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_proof_sync", "config", "roofline", "resident_witness",
                                              "latency_ms_one_at_a_time", "stage_ms") if kk in o}
+    if also_2p24 is not None:
+        out["also_2p24"] = also_2p24
+    if shard8:
+        out["also_shard8"] = {"2p%d" % o["log2n"]: o for o in shard8}
     if default_run and not args.no_server:
         out["also_server"] = server_leg()
     out["summary"] = summary_of(out)            # LAST: the scalars DESIGN.md quotes, within the tail of the line
@@ -490,7 +522,67 @@ def run(args):
     prover.lib.zk_prover_destroy(prover.h)
     if dist:
         dist.destroy_process_group()
+    if world == 1 and args.shape == "dense" and args.witness == "uniform" and k >= 20 and want_shard8(args):
+        try:
+            out["shard8"] = shard8_leg(zk, torch, wl, k, wits_dev[0], ms_per_step, latency_ms, bool(args.precomp))
+        except Exception as exc:           # noqa: BLE001  (a failed probe must not cost the line)
+            out["shard8"] = {"log2n": k, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     return out
+
+
+def want_shard8(args):
+    return not args.no_shard8 and args.log2n in (22, 24) and args.batch <= 1 and not args.window_bits
+
+
+def shard8_leg(zk, torch, wl, k, w_dev, single_ms, single_lone_ms, precomp, ranks=8):
+    """ONE rank's share of a proof split across `ranks` GPUs, measured on this GPU (what tools/shard_probe.py measures): a prover
+    created as shard 0 of `ranks` with the chain partitioned (its eighth of every MSM table — window-precomputed —, of the rows of
+    A.w / B.w and of the transforms) runs its phases through zk_shard_* with the all_to_all LEFT OUT: the exchange buffers keep
+    whatever they hold, so the result is meaningless, but kernels, sizes and launch counts are exactly a rank's.  Missing from the
+    figure: four rounds of all_to_all per proof (2 x 7/8 of a block per transform over xGMI) and the 384-byte gather of the sums."""
+    from rapidsnark_old_amd.dist import ShardedChain
+    p = ProverFromView(zk, wl, device=0, shard_index=0, shard_count=ranks, window_bits=0, timings=True, precomp=precomp, partitioned_chain=True)
+    try:
+        plan = p.info()
+        ch = ShardedChain(p.lib, p.h, None, torch.device("cuda:0"), exchange=lambda dst, src: None)
+        ch.time_phases = False
+
+        def submit():
+            ch.submit(d_wtns=w_dev.data_ptr())
+
+        for _ in range(3):
+            submit()
+            p.collect_msm()
+        launches = p.info()["kernel_launches_last_proof"]
+        torch.cuda.synchronize()
+        n1 = 8
+        t0 = time.perf_counter()
+        for _ in range(n1):
+            submit()
+            p.collect_msm()
+        one = (time.perf_counter() - t0) / n1 * 1e3
+        stage = {a: round(b, 3) for a, b in p.timings().items()}
+        n2 = 12
+        submit()
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            submit()
+            p.collect_msm()
+        p.collect_msm()
+        two = (time.perf_counter() - t0) / (n2 + 1) * 1e3
+        launches_busy = p.info()["kernel_launches_last_proof"]
+    finally:
+        p.lib.zk_prover_destroy(p.h)
+    ideal = single_ms / ranks
+    return {"log2n": k, "ranks": ranks, "rank": 0, "chain": "partitioned", "measured_on": "one GPU: this rank's kernels only, the four all_to_all rounds left out",
+            "rank_share_ms_one_at_a_time": round(one, 3), "rank_share_ms_two_in_flight": round(two, 3),
+            "single_gpu_ms_per_step": round(single_ms, 3), "single_gpu_ms_one_at_a_time": round(single_lone_ms, 3) if single_lone_ms else None,
+            "ideal_share_ms": round(ideal, 3),
+            "implied_speedup_one_at_a_time": round((single_lone_ms or single_ms) / one, 2), "implied_speedup_two_in_flight": round(single_ms / two, 2),
+            "kernel_launches_per_rank": launches, "kernel_launches_per_rank_two_in_flight": launches_busy,
+            "window_bits_h": plan["window_bits_h"], "additions_per_point_h": plan["windows_h"],
+            "window_bits_w": plan["window_bits_w"], "additions_per_point_w": plan["windows_w"],
+            "stage_ms_one_at_a_time": stage}
 
 
 def finish_roofline(out, cs, source, ceiling):
@@ -543,6 +635,14 @@ def summary_of(out):
     sv = out.get("also_server")
     if sv:
         s["server_proofs_per_s"] = sv.get("value")
+    o = out.get("also_2p24")
+    if o and o.get("value"):
+        s["ms_per_step_2p24"], s["proofs_per_s_2p24"], s["ms_per_proof_sync_2p24"] = o["ms_per_step"], o["value"], o.get("ms_per_proof_sync")
+    for tag, o in (out.get("also_shard8") or {}).items():
+        if "rank_share_ms_two_in_flight" in o:
+            s["shard8_%s_rank_ms_one_at_a_time" % tag], s["shard8_%s_rank_ms_two_in_flight" % tag] = o["rank_share_ms_one_at_a_time"], o["rank_share_ms_two_in_flight"]
+            s["shard8_%s_ideal_ms" % tag], s["shard8_%s_implied_speedup" % tag] = o["ideal_share_ms"], o["implied_speedup_two_in_flight"]
+            s["shard8_%s_launches_per_rank" % tag], s["shard8_%s_additions_per_point" % tag] = o["kernel_launches_per_rank"], o["additions_per_point_h"]
     return s
 
 

@@ -165,6 +165,7 @@ typedef struct zk_prover_plan {
     uint32_t shard_index, shard_count, chain_partitioned;
     uint64_t device_bytes_in_use;          /* HBM in use on the prover's device right now (all processes), from the runtime */
     uint64_t device_bytes_total;
+    uint64_t kernel_launches_last_proof;   /* kernel launches the most recently submitted proof took (0 before the first; a graph replay counts as none) */
 } zk_prover_plan;
 int zk_prover_info(zk_prover *p, zk_prover_plan *plan);
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);

@@ -37,11 +37,11 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256 *
 }
 
 void launch_fr_mul_vec(Fr *out, const Fr *a, const Fr *b, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_mul_vec<Fr>, dim3(grid_for(n, 256)), dim3(256), 0, s, out, a, b, n);
+    ZK_LAUNCH(k_mul_vec<Fr>, dim3(grid_for(n, 256)), dim3(256), 0, s, out, a, b, n);
     ZK_LAUNCH_OK("fr_mul_vec");
 }
 void launch_fq_mul_vec(Fq *out, const Fq *a, const Fq *b, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_mul_vec<Fq>, dim3(grid_for(n, 256)), dim3(256), 0, s, out, a, b, n);
+    ZK_LAUNCH(k_mul_vec<Fq>, dim3(grid_for(n, 256)), dim3(256), 0, s, out, a, b, n);
     ZK_LAUNCH_OK("fq_mul_vec");
 }
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev cs
 }
 
 void launch_spmv_abc(Fr *a, Fr *b, Fr *c, CsrDev csr, const Fr *wtns, uint32_t n, hipStream_t s, uint32_t vectors, uint64_t abc_stride, uint64_t wtns_stride) {
-    hipLaunchKernelGGL(k_spmv_abc, dim3((n + 255) / 256, vectors ? vectors : 1), dim3(256), 0, s, a, b, c, csr, wtns, n, abc_stride, wtns_stride);
+    ZK_LAUNCH(k_spmv_abc, dim3((n + 255) / 256, vectors ? vectors : 1), dim3(256), 0, s, a, b, c, csr, wtns, n, abc_stride, wtns_stride);
     ZK_LAUNCH_OK("spmv_abc");
 }
 
@@ -131,10 +131,10 @@ void launch_csr_build(uint32_t *rowptr, uint32_t *col, Fr *val, uint32_t *cursor
     ZK_HIP(hipMemsetAsync(cursor, 0, (size_t)rows * 4, s));
     ZK_HIP(hipMemsetAsync(err, 0, 4, s));
     const uint32_t g = grid_for(nCoefs ? nCoefs : 1, 256, 256 * 16);
-    hipLaunchKernelGGL(k_csr_count, dim3(g), dim3(256), 0, s, cursor, err, (const uint32_t *)records, nCoefs, n, nVars, row_lo, row_hi);
+    ZK_LAUNCH(k_csr_count, dim3(g), dim3(256), 0, s, cursor, err, (const uint32_t *)records, nCoefs, n, nVars, row_lo, row_hi);
     launch_exclusive_scan_u32(rowptr, cursor, rows, s);
     ZK_HIP(hipMemcpyAsync(cursor, rowptr, (size_t)rows * 4, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, col, val, cursor, (const uint32_t *)records, nCoefs, n, nVars, row_lo, row_hi);
+    ZK_LAUNCH(k_csr_fill, dim3(g), dim3(256), 0, s, col, val, cursor, (const uint32_t *)records, nCoefs, n, nVars, row_lo, row_hi);
     ZK_LAUNCH_OK("csr build");
 }
 

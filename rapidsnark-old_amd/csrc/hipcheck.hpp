@@ -35,6 +35,18 @@ struct PerDeviceOnce {
 
 }   // namespace zk
 
+// Every kernel launch of the library goes through ZK_LAUNCH: one process-wide relaxed counter, so that zk_prover_info can say how
+// many launches the last proof of a prover took (the launch count of a rank's share is what bounds a sharded proof at small
+// shares).
+namespace zk {
+inline std::atomic<uint64_t> g_kernel_launches{0};
+}
+#define ZK_LAUNCH(...)                                                        \
+    do {                                                                      \
+        ::zk::g_kernel_launches.fetch_add(1, std::memory_order_relaxed);      \
+        hipLaunchKernelGGL(__VA_ARGS__);                                      \
+    } while (0)
+
 #define ZK_HIP(expr) ::zk::hip_check((expr), #expr)
 // hipGetLastError is a thread-local read: cheap enough to run after every launcher
 #define ZK_LAUNCH_OK(what) ::zk::hip_check(hipGetLastError(), "kernel launch (" what ")")

@@ -184,7 +184,7 @@ void launch_fq_to_internal(Fq *coords, uint64_t n, hipStream_t s) {
     if (!n) return;
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
+    ZK_LAUNCH(k_fq_to_internal, dim3((uint32_t)g), dim3(256), 0, s, coords, n);
     ZK_LAUNCH_OK("fq_to_internal");
 }
 
@@ -1300,9 +1300,9 @@ uint64_t msm_reduce_scratch_points(uint32_t n_msm, MsmPlan p) {
 static void launch_scan(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s) {
     uint32_t nblocks = (total + SCAN_ELEMS - 1) / SCAN_ELEMS;
     uint32_t *block_sums = out + total + 1;
-    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, block_sums, counts, total);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums, nblocks, out + total);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, (const uint32_t *)block_sums, total);
+    ZK_LAUNCH(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, block_sums, counts, total);
+    ZK_LAUNCH(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums, nblocks, out + total);
+    ZK_LAUNCH(k_scan_add, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, out, (const uint32_t *)block_sums, total);
 }
 uint32_t msm_scan_extra_words(uint32_t total) { return (total + SCAN_ELEMS - 1) / SCAN_ELEMS; }
 void launch_exclusive_scan_u32(uint32_t *out, const uint32_t *counts, uint32_t total, hipStream_t s) { launch_scan(out, counts, total, s); }
@@ -1367,23 +1367,23 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
     const size_t lds = (size_t)bpb * 4;
     const uint32_t grid2 = ((nbins + 7u) / 8u) * 8u * slices;
     const uint32_t set_shift = p.precomp ? 32u : p.c - 1u;
-    if (n) hipLaunchKernelGGL(k_msm_digits, dim3((uint32_t)g), dim3(256), 0, s, b.codes, scalars, n, p);
-    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span());
+    if (n) ZK_LAUNCH(k_msm_digits, dim3((uint32_t)g), dim3(256), 0, s, b.codes, scalars, n, p);
+    ZK_LAUNCH(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span());
     launch_scan(b.bin_starts, b.bin_counts, nbins * nblocks, s);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), bin_scatter_lds_bytes(), s, b.lo, b.val, (const uint32_t *)b.bin_starts,
+    ZK_LAUNCH(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), bin_scatter_lds_bytes(), s, b.lo, b.val, (const uint32_t *)b.bin_starts,
                        (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span(), n, set_shift, p.batch > 1 ? p.batch_n : 0u);
-    hipLaunchKernelGGL(k_bin_count_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
+    ZK_LAUNCH(k_bin_count_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
                        (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
     launch_scan(b.starts, b.counts, tb * slices, s);
     static const bool direct = probe_env("ZKHIP_SORT_DIRECT") != nullptr;      // (-DZK_PROBES builds: the unstaged second-level scatter, for A/Bs)
     if (bpb <= 2048u && SORT_THREADS == SCAN_BLOCK && !direct)
-        hipLaunchKernelGGL(k_bin_scatter_staged, dim3(grid2), dim3(SCAN_BLOCK), (size_t)(4096 + 16 + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2, s, b.entries,
+        ZK_LAUNCH(k_bin_scatter_staged, dim3(grid2), dim3(SCAN_BLOCK), (size_t)(4096 + 16 + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2, s, b.entries,
                            (const uint32_t *)b.starts, (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins,
                            slices, tb);
     else
-        hipLaunchKernelGGL(k_bin_scatter_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
+        ZK_LAUNCH(k_bin_scatter_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.entries, (const uint32_t *)b.starts,
                            (const uint16_t *)b.lo, (const uint32_t *)b.val, (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
-    hipLaunchKernelGGL(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb, slices);
+    ZK_LAUNCH(k_msm_compact_offsets, dim3((tb + 256) / 256), dim3(256), 0, s, b.offsets, (const uint32_t *)b.starts, tb, slices);
     ZK_LAUNCH_OK("msm sort");
 }
 
@@ -1433,9 +1433,9 @@ __global__ __launch_bounds__(64) void k_precomp_normalize(Affine<F> *out, const 
 template <class F>
 static void precomp_table(Affine<F> *table, XYZZ<F> *tmp, F *pref, uint64_t n, MsmPlan p, hipStream_t s) {
     if (!n || p.W < 2) return;
-    hipLaunchKernelGGL(k_precomp_walk<F>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, tmp, (const Affine<F> *)table, n, p.c, p.W);
+    ZK_LAUNCH(k_precomp_walk<F>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, tmp, (const Affine<F> *)table, n, p.c, p.W);
     const uint64_t total = (uint64_t)(p.W - 1) * n, segs = (total + 63) / 64;
-    hipLaunchKernelGGL(k_precomp_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, table + n, (const XYZZ<F> *)tmp, pref, total);
+    ZK_LAUNCH(k_precomp_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, table + n, (const XYZZ<F> *)tmp, pref, total);
     ZK_LAUNCH_OK("window pre-computation");
 }
 void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq>(table, tmp, pref, n, p, s); }
@@ -1507,11 +1507,11 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
     uint64_t lanes = accum_lanes_for<F>(max_entries, nb, cmin, tail.chunk_max > accum_chunk_max() ? tail.chunk_max : 0u);
     if (ev) ZK_HIP(hipEventRecord(ev[0], s));          // tight bracket around the level-1 kernel (roofline timing)
     if constexpr (sizeof(F) == sizeof(Fq2)) {
-        hipLaunchKernelGGL(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK)), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,
+        ZK_LAUNCH(k_msm_accum_l1_g2s, dim3((uint32_t)((2 * lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK)), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,
                            reinterpret_cast<const G2Affine *>(batch.points[0]), batch.idx_min[0], batch.idx_sub[0], total_buckets, ws_part, ws_key, ws_flag,
                            (uint32_t)lanes, cmin);
     } else {
-        hipLaunchKernelGGL(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK), nb), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,
+        ZK_LAUNCH(k_msm_accum_l1<F>, dim3((uint32_t)((lanes + ZK_L1_BLOCK - 1) / ZK_L1_BLOCK), nb), dim3(ZK_L1_BLOCK), 0, s, buckets, offsets, entries,
                            batch, total_buckets, ws_part, ws_key, ws_flag, (uint32_t)lanes, cmin);
     }
     if (ev) ZK_HIP(hipEventRecord(ev[1], s));
@@ -1522,7 +1522,7 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
         s = tail.stream;
     }
     if (lanes > 1)
-        hipLaunchKernelGGL(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256), nb), dim3(256), 0, s, buckets,
+        ZK_LAUNCH(k_msm_accum_pair<F>, dim3((uint32_t)((lanes * LaneModel<F>::LPE + 255) / 256), nb), dim3(256), 0, s, buckets,
                            (const ACCMEM *)ws_part, ws_key, (const uint32_t *)ws_flag, (uint32_t)lanes, batch.bucket_stride, batch.ws_stride);
     uint64_t off = 0;
     while (lanes > 1) {          // a single unit has no cut runs: everything it saw was complete
@@ -1530,7 +1530,7 @@ static void launch_accum(ACCMEM *buckets, const uint32_t *offsets, const uint32_
         uint64_t noff = off + items;
         const uint64_t epw = 64u / LaneModel<F>::LPE;
         const uint64_t nl = (items + epw - 1) / epw;             // waves; each emits two slots
-        hipLaunchKernelGGL(k_msm_accum_wave<F>, dim3((uint32_t)((nl + 3) / 4), nb), dim3(256), 0, s, buckets, ws_part + off,
+        ZK_LAUNCH(k_msm_accum_wave<F>, dim3((uint32_t)((nl + 3) / 4), nb), dim3(256), 0, s, buckets, ws_part + off,
                            ws_key + off, ws_flag + off, (uint32_t)items, ws_part + noff, ws_key + noff, ws_flag + noff, (uint32_t)nl,
                            batch.bucket_stride, batch.ws_stride);
         off = noff;
@@ -1579,8 +1579,8 @@ static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *b
         const uint32_t NE = REDUCE_THREADS / LaneModel<F>::LPE, groups = n_msm * p.sets;
         const uint32_t nblk = p.nbuckets > NE ? p.nbuckets / NE : 1u;
         const size_t lds = REDUCE_THREADS * sizeof(XYZZ<typename LaneModel<F>::R>);
-        hipLaunchKernelGGL(k_msm_reduce_bits_block<F>, dim3(nblk, groups), dim3(REDUCE_THREADS), lds, s, scratch, window_sums, buckets, p.nbuckets, p.c, nblk);
-        if (nblk > 1) hipLaunchKernelGGL(k_msm_reduce_bits_top<F>, dim3(groups), dim3(REDUCE_THREADS), 0, s, window_sums, scratch, nblk, p.c);
+        ZK_LAUNCH(k_msm_reduce_bits_block<F>, dim3(nblk, groups), dim3(REDUCE_THREADS), lds, s, scratch, window_sums, buckets, p.nbuckets, p.c, nblk);
+        if (nblk > 1) ZK_LAUNCH(k_msm_reduce_bits_top<F>, dim3(groups), dim3(REDUCE_THREADS), 0, s, window_sums, scratch, nblk, p.c);
         ZK_LAUNCH_OK("msm bucket reduction (bit sums)");
         return;
     }
@@ -1589,16 +1589,16 @@ static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *b
     const uint32_t TREE_IN = tree_in<F>();
     auto chunks = [&](ACCMEM *out, uint32_t out_stride, const ACCMEM *in, uint32_t n, uint32_t chunk) {      // sum_k (k+1) in[k] over n points per set -> n / chunk shares
         const uint32_t total_chunks = groups * (n / chunk);
-        hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((total_chunks * LaneModel<F>::LPE + 127) / 128), dim3(128), 0, s, out, out_stride, in, n, chunk, total_chunks);
+        ZK_LAUNCH(k_msm_reduce_chunks<F>, dim3((total_chunks * LaneModel<F>::LPE + 127) / 128), dim3(128), 0, s, out, out_stride, in, n, chunk, total_chunks);
     };
     if (const uint32_t ch = reduce_split_for(p)) {
         const uint32_t L = p.nbuckets / ch, top = reduce_split_top(L), nx = L / top, per = nx + L;      // per set: nx shares, then the L points of the A level
         ACCMEM *T = scratch, *Y = T + (uint64_t)groups * L, *P = Y + (uint64_t)groups * per;
-        hipLaunchKernelGGL(k_msm_reduce_split<F>, dim3((L * LaneModel<F>::LPE + 127) / 128, groups), dim3(128), 0, s, Y + nx, per, T, buckets, p.nbuckets, ch, L);
+        ZK_LAUNCH(k_msm_reduce_split<F>, dim3((L * LaneModel<F>::LPE + 127) / 128, groups), dim3(128), 0, s, Y + nx, per, T, buckets, p.nbuckets, ch, L);
         chunks(Y, per, T, L, top);
         const uint32_t bx = nx / TREE_IN, ba = L / TREE_IN;        // whole workgroups of each kind (reduce_split_for)
-        hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(bx + ba, groups), dim3(REDUCE_THREADS), lds, s, P, window_sums, (const ACCMEM *)Y, per, 0u);
-        hipLaunchKernelGGL(k_msm_reduce_final2<F>, dim3(groups), dim3(REDUCE_THREADS), lds, s, window_sums, (const ACCMEM *)P, bx, ba, (uint32_t)__builtin_ctz(ch));
+        ZK_LAUNCH(k_msm_reduce_tree<F>, dim3(bx + ba, groups), dim3(REDUCE_THREADS), lds, s, P, window_sums, (const ACCMEM *)Y, per, 0u);
+        ZK_LAUNCH(k_msm_reduce_final2<F>, dim3(groups), dim3(REDUCE_THREADS), lds, s, window_sums, (const ACCMEM *)P, bx, ba, (uint32_t)__builtin_ctz(ch));
         ZK_LAUNCH_OK("msm bucket reduction (split)");
         return;
     }
@@ -1610,7 +1610,7 @@ static void launch_reduce(XYZZ<F> *window_sums, ACCMEM *scratch, const ACCMEM *b
         const uint32_t blocks = (cnt + TREE_IN - 1) / TREE_IN;
         const bool last = blocks == 1;
         ACCMEM *out = in + (uint64_t)groups * cnt;
-        hipLaunchKernelGGL(k_msm_reduce_tree<F>, dim3(blocks, groups), dim3(REDUCE_THREADS), lds, s, out, window_sums, (const ACCMEM *)in, cnt, last ? 1u : 0u);
+        ZK_LAUNCH(k_msm_reduce_tree<F>, dim3(blocks, groups), dim3(REDUCE_THREADS), lds, s, out, window_sums, (const ACCMEM *)in, cnt, last ? 1u : 0u);
         if (last) break;
         in = out;
         cnt = blocks;

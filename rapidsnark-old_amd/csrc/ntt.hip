@@ -191,9 +191,9 @@ static void run_pass(Fr *data, uint64_t stride, uint32_t batch, const TwEntry *t
         attr.done();
     }
     if (ntt_threads() == 512u)
-        hipLaunchKernelGGL((k_ntt_pass<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, tw, premul, logn, lo, t, q);
+        ZK_LAUNCH((k_ntt_pass<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, tw, premul, logn, lo, t, q);
     else
-        hipLaunchKernelGGL((k_ntt_pass<DIF, 256>), dim3(tiles, batch), dim3(256), shmem, s, data, stride, tw, premul, logn, lo, t, q);
+        ZK_LAUNCH((k_ntt_pass<DIF, 256>), dim3(tiles, batch), dim3(256), shmem, s, data, stride, tw, premul, logn, lo, t, q);
     ZK_LAUNCH_OK("ntt pass");
 }
 
@@ -292,7 +292,7 @@ void launch_ntt_cross(bool inverse, const Fr *xb, uint64_t in_src_stride, uint64
     for (int i = 0; i < 8; i++) out.base[i] = i < (1 << log_shards) ? out_base[i] : nullptr;
     const dim3 grid((uint32_t)((chunk + 255) / 256), batch), blk(256);
     const TwEntry *tw = inverse ? tb.inv : tb.fwd;
-#define ZK_CROSS(D, L) hipLaunchKernelGGL((k_ntt_cross<D, L>), grid, blk, 0, s, xb, in_src_stride, in_poly_stride, out, out_poly_stride, out_offset, tw, tb.logn, rank, chunk, block)
+#define ZK_CROSS(D, L) ZK_LAUNCH((k_ntt_cross<D, L>), grid, blk, 0, s, xb, in_src_stride, in_poly_stride, out, out_poly_stride, out_offset, tw, tb.logn, rank, chunk, block)
     if (inverse) {
         if (log_shards == 1) ZK_CROSS(true, 1); else if (log_shards == 2) ZK_CROSS(true, 2); else ZK_CROSS(true, 3);
     } else {
@@ -325,8 +325,8 @@ static void chunk_move(bool gather, Fr *const far_base[8], Fr *blockdata, uint64
     ChunkDst d;
     for (int i = 0; i < 8; i++) d.base[i] = i < (1 << log_shards) ? far_base[i] : nullptr;
     const dim3 grid((uint32_t)((block + 255) / 256), batch);
-    if (gather) hipLaunchKernelGGL(k_chunk_move<true>, grid, dim3(256), 0, s, d, blockdata, chunk, block, poly_stride, offset);
-    else hipLaunchKernelGGL(k_chunk_move<false>, grid, dim3(256), 0, s, d, blockdata, chunk, block, poly_stride, offset);
+    if (gather) ZK_LAUNCH(k_chunk_move<true>, grid, dim3(256), 0, s, d, blockdata, chunk, block, poly_stride, offset);
+    else ZK_LAUNCH(k_chunk_move<false>, grid, dim3(256), 0, s, d, blockdata, chunk, block, poly_stride, offset);
     ZK_LAUNCH_OK("chunk scatter/gather");
 }
 void launch_chunk_scatter(Fr *const xb_of_gpu[8], const Fr *blockdata, uint32_t batch, uint32_t logn, uint32_t log_shards, uint32_t rank,
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_scale_table(Fr *data, uint64_t stride_e
 void launch_fr_scale_by_table(Fr *data, uint64_t stride, uint32_t batch, const Fr *table, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_scale_table, dim3((uint32_t)g, batch), dim3(256), 0, s, data, stride, table, n);
+    ZK_LAUNCH(k_scale_table, dim3((uint32_t)g, batch), dim3(256), 0, s, data, stride, table, n);
     ZK_LAUNCH_OK("scale by table");
 }
 
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_scale_const(Fr *x, const Fr *k, uint64_
 void launch_fr_scale_const(Fr *data, const Fr *k, uint64_t n, hipStream_t s) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_scale_const, dim3((uint32_t)g), dim3(256), 0, s, data, k, n);
+    ZK_LAUNCH(k_scale_const, dim3((uint32_t)g), dim3(256), 0, s, data, k, n);
     ZK_LAUNCH_OK("scale");
 }
 
@@ -394,7 +394,7 @@ void launch_bitrev_permute(Fr *data, uint32_t logn, hipStream_t s) {
     uint64_t n = 1ull << logn;
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_bitrev, dim3((uint32_t)g), dim3(256), 0, s, data, logn);
+    ZK_LAUNCH(k_bitrev, dim3((uint32_t)g), dim3(256), 0, s, data, logn);
     ZK_LAUNCH_OK("bit reversal");
 }
 
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_abc_to_h(Fr *h, const Fr *a, const Fr *
 void launch_abc_to_h(Fr *h, const Fr *a, const Fr *b, const Fr *c, uint64_t n, hipStream_t s, uint32_t vectors, uint64_t abc_stride) {
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_abc_to_h, dim3((uint32_t)g, vectors ? vectors : 1), dim3(256), 0, s, h, a, b, c, n, abc_stride);
+    ZK_LAUNCH(k_abc_to_h, dim3((uint32_t)g, vectors ? vectors : 1), dim3(256), 0, s, h, a, b, c, n, abc_stride);
     ZK_LAUNCH_OK("abc_to_h");
 }
 
@@ -437,14 +437,14 @@ void launch_fr_to_internal(Fr *x, uint64_t n, int times, hipStream_t s) {
     if (!n) return;
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 1, times);
+    ZK_LAUNCH(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 1, times);
     ZK_LAUNCH_OK("fr_to_internal");
 }
 void launch_fr_from_internal(Fr *x, uint64_t n, hipStream_t s) {
     if (!n) return;
     uint64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 0, 1);
+    ZK_LAUNCH(k_fr_convert, dim3((uint32_t)g), dim3(256), 0, s, x, n, 0, 1);
     ZK_LAUNCH_OK("fr_from_internal");
 }
 
@@ -509,7 +509,7 @@ void launch_ntt_build_tables(TwEntry *fwd, TwEntry *inv, Fr *coset, Fr *ninv, ui
     uint64_t n = 1ull << logn;
     uint64_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_build_tables, dim3((uint32_t)g), dim3(256), 0, s, fwd, inv, coset, ninv, logn);
+    ZK_LAUNCH(k_build_tables, dim3((uint32_t)g), dim3(256), 0, s, fwd, inv, coset, ninv, logn);
     ZK_LAUNCH_OK("twiddle tables");
 }
 

@@ -510,7 +510,7 @@ void NttPair::build(uint32_t logn_global, uint32_t logn_local, uint32_t block_in
     for (uint32_t i = 0; i < lg; i++) rho |= ((block_index >> i) & 1u) << (lg - 1 - i);
     uint64_t grid = ((n > 2048 ? n : 2048) + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_pair_tables, dim3((uint32_t)grid), dim3(256), 0, s, rfwd, rinv, tinv, tfwd, dtab, t2inv, t2fwd, L, Lg, rho, m, g[0], plain ? 1u : 0u);
+    ZK_LAUNCH(k_pair_tables, dim3((uint32_t)grid), dim3(256), 0, s, rfwd, rinv, tinv, tfwd, dtab, t2inv, t2fwd, L, Lg, rho, m, g[0], plain ? 1u : 0u);
     ZK_LAUNCH_OK("ntt pair tables");
 }
 void NttPair::release() {
@@ -552,10 +552,10 @@ static void run_outer(Fr *data, uint64_t stride, uint32_t batch, const NttPair &
     lds_opt_in();
     if (VB == 12) {
         const size_t shmem = (size_t)9 * 4096 * 4;
-        hipLaunchKernelGGL((k_ntt_outer<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, o);
+        ZK_LAUNCH((k_ntt_outer<DIF, 512>), dim3(tiles, batch), dim3(512), shmem, s, data, stride, o);
     } else {
         const size_t shmem = (size_t)9 * 2048 * 4;
-        hipLaunchKernelGGL((k_ntt_outer<DIF, 256>), dim3(tiles, batch), dim3(256), shmem, s, data, stride, o);
+        ZK_LAUNCH((k_ntt_outer<DIF, 256>), dim3(tiles, batch), dim3(256), shmem, s, data, stride, o);
     }
     ZK_LAUNCH_OK("ntt outer pass");
 }
@@ -579,7 +579,7 @@ static void run_mid(Fr *data, const Fr *src, uint64_t stride, uint32_t batch, co
     const uint32_t wgs = (uint32_t)(((1ull << tb.L) + 2047) >> 11);
     d.tiles = wgs;
     const size_t shmem = (size_t)9 * 2048 * 4;
-    hipLaunchKernelGGL(k_ntt_mid<MODE>, dim3(wgs * batch), dim3(256), shmem, s, data, src, stride, d);
+    ZK_LAUNCH(k_ntt_mid<MODE>, dim3(wgs * batch), dim3(256), shmem, s, data, src, stride, d);
     ZK_LAUNCH_OK("ntt middle pass");
 }
 template <bool DIF>

@@ -477,6 +477,7 @@ int zk_prover_info(zk_prover *p, zk_prover_plan *plan) {
             HIP_TRY(hipMemGetInfo(&fr, &tot));
             o.device_bytes_in_use = tot - fr; o.device_bytes_total = tot;
         }
+        o.kernel_launches_last_proof = p->launches_last_proof;
         const uint32_t nb = plan->size < sizeof o ? plan->size : (uint32_t)sizeof o;
         o.size = nb;
         memcpy(plan, &o, nb);

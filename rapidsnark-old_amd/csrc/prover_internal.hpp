@@ -366,6 +366,7 @@ struct zk_prover {
 
     double timings[ZK_T_COUNT] = {0};
     uint32_t accum_launches = 0;
+    uint64_t launches_at_front = 0, launches_last_proof = 0;     // hipcheck.hpp's launch counter around the last submitted proof
 
     ~zk_prover() {
         // proofs may still be in flight (submitted, never collected): drain before anything is released

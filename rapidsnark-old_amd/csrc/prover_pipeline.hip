@@ -323,6 +323,7 @@ int phase_front(zk_prover *p, const Fr *d_wtns, const uint8_t *h_wtns, const uin
     }
     PhaseCtx c(p, si);
     zk_prover::ProofSlot &q = c.q;
+    if (!p->capturing) p->launches_at_front = g_kernel_launches.load(std::memory_order_relaxed);
     bool staged = h_wtns != nullptr;
     q.count = 1;
     if (bi) {
@@ -503,6 +504,8 @@ void phase_back(zk_prover *p) {
     HIP_TRY(hipEventRecord(q.ev_done, sf));
     if (p->capturing && sf != s) HIP_TRY(hipStreamWaitEvent(s, q.ev_done, 0));     // every forked stream rejoins the origin
     HIP_TRY(hipGetLastError());          // nothing of the ~100 launches above may have been refused
+    // kernel launches of this proof (zk_prover_info): exact while one thread submits at a time in the process
+    if (!p->capturing) p->launches_last_proof = g_kernel_launches.load(std::memory_order_relaxed) - p->launches_at_front;
     q.busy = true;
     q.via_graph = false;
     p->phase_open = -1;

@@ -79,8 +79,8 @@ template <class F>
 static void chain(Affine<F> *d_out, XYZZ<F> *d_tmp, F *d_pref, const Affine<F> &P0, const Affine<F> &Q, uint64_t n, hipStream_t s) {
     uint64_t segs = (n + CHAIN_SEG - 1) / CHAIN_SEG;
     uint32_t blocks = (uint32_t)((segs + 63) / 64);
-    hipLaunchKernelGGL(k_chain_walk<F>, dim3(blocks), dim3(64), 0, s, d_tmp, P0, Q, n);
-    hipLaunchKernelGGL(k_chain_normalize<F>, dim3(blocks), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
+    ZK_LAUNCH(k_chain_walk<F>, dim3(blocks), dim3(64), 0, s, d_tmp, P0, Q, n);
+    ZK_LAUNCH(k_chain_normalize<F>, dim3(blocks), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
     ZK_LAUNCH_OK("synthetic chain");
 }
 
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(64) void k_fixed_base(XYZZ<F> *tmp, Affine<F> B, co
 }
 template <class F>
 static void fixed_base(Affine<F> *d_out, XYZZ<F> *d_tmp, F *d_pref, const Affine<F> &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_fixed_base<F>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, d_tmp, B, d_scalars, n);
+    ZK_LAUNCH(k_fixed_base<F>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, d_tmp, B, d_scalars, n);
     uint64_t segs = (n + CHAIN_SEG - 1) / CHAIN_SEG;
-    hipLaunchKernelGGL(k_chain_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
+    ZK_LAUNCH(k_chain_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, d_out, (const XYZZ<F> *)d_tmp, d_pref, n);
     ZK_LAUNCH_OK("fixed-base batch");
 }
 void launch_fixed_base_g1(G1Affine *d_out, G1XYZZ *d_tmp, Fq *d_pref, const G1Affine &B, const uint32_t *d_scalars, uint64_t n, hipStream_t s) {

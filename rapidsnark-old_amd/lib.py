@@ -47,7 +47,8 @@ class zk_prover_plan(C.Structure):
                 ("windows_w", C.c_uint32), ("precomputed_tables", C.c_uint32), ("msm_a_b1_c_one_launch", C.c_uint32), ("lanes", C.c_uint32),
                 ("follow_up_streams", C.c_uint32), ("max_in_flight", C.c_uint32), ("depth_host_witness", C.c_uint32),
                 ("depth_resident_witness", C.c_uint32), ("batch", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
-                ("chain_partitioned", C.c_uint32), ("device_bytes_in_use", C.c_uint64), ("device_bytes_total", C.c_uint64)]
+                ("chain_partitioned", C.c_uint32), ("device_bytes_in_use", C.c_uint64), ("device_bytes_total", C.c_uint64),
+                ("kernel_launches_last_proof", C.c_uint64)]
 
 
 def prover_info(lib, handle):

@@ -136,3 +136,20 @@ def test_leg_stats_cuts_a_trace_at_the_marker_launches(tmp_path):
     assert int(l1["Calls"]) == 3 and float(l1["AverageNs"]) == 4000.0 and int(float(l1["TotalDurationNs"])) == 12000
     lone = list(csv.DictReader(open(tmp_path / "t_kernel_stats_2p22_lone_resident.csv")))
     assert {r["Name"].split("<")[0].split("::")[-1].split("(")[0] for r in lone} == {"k_msm_accum_l1", "k_mul_vec"}     # the small k_mul_vec stays a kernel of the leg
+
+
+def test_summary_carries_the_2p24_leg_and_the_rank_share_of_eight():
+    """The scaling evidence of a one-GPU run (also_2p24, also_shard8) must be among the flat scalars at the END of the line: a record
+    that keeps only the tail of stdout still holds them.  A probe that failed is reported as such and adds no scalar."""
+    out = {"value": 32.0, "ms_per_step": 31.2, "roofline": {"frac": 0.008, "launch_ms": 6.2, "g2_launch_ms": 16.0, "whole_proof_frac": 0.024},
+           "also_2p24": {"value": 8.5, "ms_per_step": 117.7, "ms_per_proof_sync": 133.1},
+           "also_shard8": {"2p22": {"log2n": 22, "rank_share_ms_one_at_a_time": 5.8, "rank_share_ms_two_in_flight": 5.0, "ideal_share_ms": 3.9,
+                                    "implied_speedup_two_in_flight": 6.24, "kernel_launches_per_rank": 101, "additions_per_point_h": 15},
+                           "2p24": {"log2n": 24, "error": "HipError: out of memory"}}}
+    s = bench.summary_of(out)
+    assert s["ms_per_step_2p24"] == 117.7 and s["proofs_per_s_2p24"] == 8.5 and s["ms_per_proof_sync_2p24"] == 133.1
+    assert s["shard8_2p22_rank_ms_two_in_flight"] == 5.0 and s["shard8_2p22_ideal_ms"] == 3.9 and s["shard8_2p22_implied_speedup"] == 6.24
+    assert s["shard8_2p22_launches_per_rank"] == 101 and s["shard8_2p22_additions_per_point"] == 15
+    assert not any(kk.startswith("shard8_2p24") for kk in s)
+    out["also_2p24"] = {"value": None, "error": "x"}
+    assert "ms_per_step_2p24" not in bench.summary_of(out)
