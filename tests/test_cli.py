@@ -83,6 +83,19 @@ def test_parity_kit_self_check_on_our_prover():
 
 
 @pytest.mark.gpu
+def test_parity_kit_files_mode_on_our_prover():
+    """refcheck.py --ours --files ZKEY WTNS: the one-step pin for files that are not fixtures (what snarkjs writes), self-checked with
+    this repository's prover on one side and the C restatement on the other, at the kit's default (r, s)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refcheck", "refcheck.py"), "--ours", "--files",
+                          golden_path("multiplier2", "circuit.zkey"), golden_path("multiplier2", "witness.wtns")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("IDENTICAL") == 2 and "PINNED" in res.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0,0,0,0", "0,0,0"])
 def test_cli_over_several_devices(tmp_path, devices):
     """ZKHIP_DEVICES=...: the reference's own argv, one proof split over several GPUs (zk_multi_prover; here

@@ -178,6 +178,22 @@ def test_parity_kit_shim_serves_r_then_s(tmp_path):
     assert out == [r.to_bytes(31, "little").hex(), s.to_bytes(31, "little").hex()]
 
 
+def test_parity_kit_files_mode_oracle_side():
+    """tools/refcheck/refcheck.py --files ZKEY WTNS (snarkjs-made files against a real rapidsnark binary):
+    the side the binary's output is compared with — the C restatement + the library's host-only JSON writers — reproduces the
+    committed Multiplier2 fixture byte for byte when given the fixture's (r, s)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("refcheck_kit", os.path.join(ROOT, "tools", "refcheck", "refcheck.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    d = os.path.join(ROOT, "tests", "golden", "multiplier2")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    pj, qj = kit.oracle_jsons(os.path.join(d, "circuit.zkey"), os.path.join(d, "witness.wtns"), int(meta["r"]), int(meta["s"]))
+    assert pj == open(os.path.join(d, "proof.json"), "rb").read()
+    assert qj == open(os.path.join(d, "public.json"), "rb").read()
+
+
 def test_assemble_random_scalars_against_the_group_law(zk):
     """The tail's scalar multiplications use fixed-base tables for delta and one joint signed-window pass
     for s*pi_a + r*pi_b1 (csrc/host_tail.cpp): check the assembled proof against groth16.cpp:222-246
