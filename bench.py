@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--no-realistic", action="store_true", help="skip the also_realistic leg of a default (2^22, N = 1) run (--no-cpu skips it too)")
     ap.add_argument("--precomp", type=int, default=1,
                     help="1 (default) = window-precomputed point tables resident in HBM (ZK_FLAG_PRECOMP: one-off work in create, like\n"
-                         "the reference's makeProver it is outside the timed prove()); 0 = tables exactly as in the zkey")
+                         "the reference's makeProver it is outside the timed prove()); 0 = tables exactly as in the zkey;\n"
+                         "2 = rows for every second window (ZK_FLAG_PRECOMP_HALF: 7 instead of 13 x the table memory, two bucket reductions per MSM)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1 (default, single GPU): consecutive proofs overlap through zk_prove_dev_submit / zk_prove_collect "
                          "(two in flight); 0: strictly one proof at a time (zk_prove_dev)")
@@ -213,7 +214,7 @@ def run(args):
         raise SystemExit("--chain partitioned needs 2, 4 or 8 ranks")
     sparse = bool(args.sparse_witness) if args.sparse_witness >= 0 else (args.witness == "realistic" and bool(args.precomp) and not args.window_bits)
     prover = ProverFromView(zk, wl, device=local_rank, shard_index=rank, shard_count=world,
-                            window_bits=args.window_bits, timings=True, precomp=bool(args.precomp), partitioned_chain=partitioned,
+                            window_bits=args.window_bits, timings=True, precomp=args.precomp, partitioned_chain=partitioned,
                             batch=args.batch if world == 1 else 0, sparse_witness=sparse)
     t_create = time.time() - t0
     plan = prover.info()                    # zk_prover_info: what the library decided (windows, A|B1|C in one launch, lanes, depths)
@@ -429,7 +430,7 @@ def run(args):
     # only").  Same timing rules: barrier + synchronize on both sides, max over ranks; value = N * K proofs / that time.
     replicas = None
     if world > 1 and not args.no_replicas:
-        replicas = replicas_leg(zk, wl, local_rank, k, wits_host, args.steps, bool(args.precomp), dist, xdev, torch, world)
+        replicas = replicas_leg(zk, wl, local_rank, k, wits_host, args.steps, args.precomp, dist, xdev, torch, world)
 
     latency_ms = latency_host_ms = None
     lone = {}
@@ -463,7 +464,7 @@ def run(args):
     config = {"workload": "synthetic BN254 zkey, 2^%d constraints (%s, nCoefs=%d), %s witness" % (k, shape_txt, wl["nCoefs"], "uniform random" if args.witness == "uniform" else "realistic (80% {0,1}, 15% <2^32, 5% full)"),
               "shape": args.shape, "log2n": k,
               "parallelism": "msm-point-shard x%d" % world + (", chain partitioned (4 x all_to_all per proof)" if partitioned else (", chain replicated" if world > 1 else "")),
-              "window_bits": plan["window_bits_h"], "windows": plan["windows_h"], "precomputed_window_tables": bool(plan["precomputed_tables"]),
+              "window_bits": plan["window_bits_h"], "windows": plan["windows_h"], "precomputed_window_tables": bool(plan["precomputed_tables"]), "table_rows": plan.get("table_rows_h", 0), "bucket_sets_per_msm": plan.get("bucket_sets_h", 0),
               "witness_msm_window_bits": plan["window_bits_w"] if plan["window_bits_w"] != plan["window_bits_h"] else None,
               "msm_a_b1_c_in_one_launch": bool(plan["msm_a_b1_c_one_launch"]), "lanes": plan["lanes"],
               "proofs_in_flight": depth_for(headline_hbm) if pipelined else 1,
@@ -489,7 +490,7 @@ def run(args):
                 "clock_ghz": ck.get("clock_ghz"), "power_w": ck.get("power_w"), "clock_samples": ck.get("samples"),
                 "simds": torch.cuda.get_device_properties(local_rank).multi_processor_count * 4,
                 # what the kernel's largest launch gathers from: W rows of 64 B per point of every table the launch walks
-                "gather_table_bytes": int((3 if plan["msm_a_b1_c_one_launch"] else 1) * (plan["windows_h"] if plan["precomputed_tables"] else 1) * pts * 64),
+                "gather_table_bytes": int((3 if plan["msm_a_b1_c_one_launch"] else 1) * max(1, plan.get("table_rows_h", 1)) * pts * 64),
                 "whole_proof_algorithmic_bytes": 1424 * n, "whole_proof_frac": round(1424 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
 
     out = {
@@ -524,7 +525,7 @@ def run(args):
         dist.destroy_process_group()
     if world == 1 and args.shape == "dense" and args.witness == "uniform" and k >= 20 and want_shard8(args):
         try:
-            out["shard8"] = shard8_leg(zk, torch, wl, k, wits_dev[0], ms_per_step, latency_ms, bool(args.precomp))
+            out["shard8"] = shard8_leg(zk, torch, wl, k, wits_dev[0], ms_per_step, latency_ms, args.precomp)
         except Exception as exc:           # noqa: BLE001  (a failed probe must not cost the line)
             out["shard8"] = {"log2n": k, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     return out
@@ -659,7 +660,7 @@ def counters_child(args):
         shape, k = spec[leg]
         realistic = shape == "circuit"
         wl = synth.workload(k, zk.synth_chain_g1, zk.synth_chain_g2, zk.g1_mul, zk.g2_mul, synth.g1_gen_bytes(), synth.g2_gen_bytes(), shape=shape)
-        p = ProverFromView(zk, wl, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=bool(args.precomp),
+        p = ProverFromView(zk, wl, device=0, shard_index=0, shard_count=1, window_bits=0, timings=False, precomp=args.precomp,
                            sparse_witness=realistic and bool(args.precomp))
         w = torch.from_numpy(synth.make_witness(k, seed=1, kind="realistic" if realistic else "uniform", n_vars=wl["nVars"])).cuda()
         torch.cuda.synchronize()

@@ -68,6 +68,12 @@ typedef struct zk_opts {
 #define ZK_FLAG_PRECOMP 2u   /* window-precomputed point tables: W x the table memory in HBM and a longer
                               * zk_prover_create, ~19 % fewer point additions per proof (same results) */
 
+#define ZK_FLAG_PRECOMP_HALF 16u   /* (implies ZK_FLAG_PRECOMP) table rows for every SECOND window only: ceil(W/2) x the table memory
+                              * instead of W x (7 instead of 13 at c = 20) and the same additions per point.  The digits of the odd
+                              * windows add the neighbouring even window's row into a second bucket set, whose sum the host doubles
+                              * c times: two bucket reductions per MSM instead of one.  For provers that hold several keys
+                              * (proverServer, src/main_proofserver.cpp:12-26) and for circuits whose full tables do not fit (2^25
+                              * on one MI355X).  Same proofs.  Not with opts.batch. */
 #define ZK_FLAG_SPARSE_WITNESS 8u   /* with ZK_FLAG_PRECOMP: the four witness MSMs (A, B1, B2, C; src/groth16.cpp:180-204) use a
                               * 16-bit window (2^15 buckets per set) instead of the size-based one (2^19 at 2^22 constraints).
                               * For CIRCUIT witnesses — mostly 0, 1 and small values: few non-zero digits — the additions are few
@@ -154,7 +160,7 @@ typedef struct zk_prover_plan {
     uint32_t size;
     uint32_t window_bits_h, windows_h;     /* Pippenger window c of MSM H; digits = point additions per point */
     uint32_t window_bits_w, windows_w;     /* the same for the witness MSMs A, B1, B2, C (differs with ZK_FLAG_SPARSE_WITNESS) */
-    uint32_t precomputed_tables;           /* ZK_FLAG_PRECOMP in effect */
+    uint32_t precomputed_tables;           /* 0: tables as in the zkey; 1: ZK_FLAG_PRECOMP (a row per window); 2: ZK_FLAG_PRECOMP_HALF (a row per second window) */
     uint32_t msm_a_b1_c_one_launch;        /* MSM A, B1, C as ONE set of launches over three tables (blockIdx.y) */
     uint32_t lanes;                        /* independent sets of compute streams: proof k runs on lane k % lanes */
     uint32_t follow_up_streams;            /* high-priority streams for merges / reductions (sharded provers) */
@@ -166,6 +172,8 @@ typedef struct zk_prover_plan {
     uint64_t device_bytes_in_use;          /* HBM in use on the prover's device right now (all processes), from the runtime */
     uint64_t device_bytes_total;
     uint64_t kernel_launches_last_proof;   /* kernel launches the most recently submitted proof took (0 before the first; a graph replay counts as none) */
+    uint32_t table_rows_h, table_rows_w;   /* rows of n points per table (x the zkey's table memory): windows_* with ZK_FLAG_PRECOMP, ceil(windows_* / 2) with _HALF, else 1 */
+    uint32_t bucket_sets_h, bucket_sets_w; /* bucket sets (= bucket reductions) per MSM: 1 with ZK_FLAG_PRECOMP, 2 with _HALF, windows_* with plain tables */
 } zk_prover_plan;
 int zk_prover_info(zk_prover *p, zk_prover_plan *plan);
 int zk_prove_msm_collect(zk_prover *p, zk_msm_sums *partial);

@@ -352,7 +352,8 @@ int HostTail::finish_from_records(const uint8_t vk_alpha1[64], const uint8_t vk_
     }
     G1P a, b1, c, h;
     G2P b2;
-    if (Ww > 1 || Wh > 1) {            // plain tables: five Horner chains of W*c doublings, one host thread each
+    if (Ww > 2 || Wh > 2) {            // plain tables: five Horner chains of W*c doublings, one host thread each (two sets — rows for every
+                                       // second window — are c doublings per MSM: inline)
         std::thread t1([&] { a = horner<G1P>(wa, Ww, cw, rcw); });
         std::thread t2([&] { b1 = horner<G1P>(wb1, Ww, cw, rcw); });
         std::thread t3([&] { c = horner<G1P>(wc, Ww, cw, rcw); });

@@ -113,13 +113,17 @@ struct MsmPlan {
     uint32_t c;          // window bits
     uint32_t W;          // digit windows = ceil(256 / c)
     uint32_t nbuckets;   // buckets per bucket set = 2^(c-1)
-    uint32_t sets;       // bucket sets: W normally, 1 with window-precomputed tables
-    uint32_t precomp;    // 1: tables hold 2^(c*j) P_i for j < W and every window shares one bucket set
+    uint32_t sets;       // bucket sets: W normally, 1 with window-precomputed tables (2 with rows for every second window)
+    uint32_t precomp;    // 1: tables hold 2^(c*j) P_i for j < W and every window shares one bucket set;
+                         // 2: rows for the EVEN windows only (row u = 2^(2c*u) P_i, ceil(W/2) rows): window 2u + 1 uses row u too and
+                         //    adds into a second bucket set, whose sum the host doubles c times (Horner over the two sets)
     uint32_t batch;      // >= 1: the scalar vector is `batch` vectors of batch_n scalars back to back (several small proofs
     uint32_t batch_n;    //   in one set of launches): vector v has its own bucket set v (sets == batch), every vector
 };                       //   indexes the SAME table rows.  Window-precomputed tables only.
 // n = scalars per vector; batch > 1 => the sort runs over batch * n scalars
-MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp = false, uint32_t batch = 1);
+MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, uint32_t precomp = 0, uint32_t batch = 1);
+// rows of n points a table of this plan holds (1 = the points themselves)
+inline uint32_t msm_table_rows(const MsmPlan &p) { return p.precomp ? (p.W + p.precomp - 1) / p.precomp : 1u; }
 
 // Digit recoding + counting sort of a scalar vector into bucket order (shared by every MSM over
 // that vector).  Buffer sizes (in elements) come from msm_sort_sizes(); unused ones are 0.

@@ -31,7 +31,8 @@ namespace zk {
 #define REDUCE_CHUNK 16u
 #define REDUCE_THREADS 256u
 
-MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp, uint32_t batch) {
+MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, uint32_t precomp, uint32_t batch) {
+    if (precomp > 2) throw std::invalid_argument("table mode: 0 (as in the zkey), 1 (a row per window) or 2 (a row per second window)");
     MsmPlan p;
     uint32_t lg = 0;
     while ((1ull << (lg + 1)) <= n) lg++;
@@ -73,12 +74,12 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, bool precomp, uint32_t b
         }
     }
     p.nbuckets = 1u << (c - 1);
-    p.precomp = precomp ? 1u : 0u;
-    p.sets = precomp ? 1u : p.W;
+    p.precomp = precomp;
+    p.sets = precomp ? precomp : p.W;
     p.batch = 1;
     p.batch_n = 0;
     if (batch > 1) {
-        if (!precomp) throw std::invalid_argument("batched MSMs need window-precomputed tables");
+        if (precomp != 1) throw std::invalid_argument("batched MSMs need window-precomputed tables with a row per window");
         p.batch = batch;
         p.batch_n = (uint32_t)n;
         p.sets = batch;
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *
     uint64_t st = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t c = p.c, W = p.W;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    const uint32_t set_stride = p.precomp ? 0u : p.nbuckets;
+    // bucket set of window w: its own with plain tables, the one shared set with a row per window, set w & 1 with a row per second window
+    const uint32_t set_stride = p.precomp == 1 ? 0u : p.nbuckets, set_mask = p.precomp == 2 ? 1u : 0xffffffffu;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
         Fr s = load_el(scalars + i);
         const uint32_t vec_base = p.batch > 1 ? (uint32_t)(i / p.batch_n) * p.nbuckets : 0u;      // bucket set of this scalar's vector
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(uint32_t *digits, const Fr *
             const bool neg = d >= half;                  // digits in [-2^(c-1), 2^(c-1) - 1]
             carry = neg ? 1u : 0u;
             uint32_t mag = neg ? (1u << c) - d : d;      // 0 when raw = 2^c - 1 and carry = 1
-            uint32_t code = mag ? ((mag - 1u + w * set_stride + vec_base) | (neg ? 0x80000000u : 0u)) : CODE32_ZERO;
+            uint32_t code = mag ? ((mag - 1u + (w & set_mask) * set_stride + vec_base) | (neg ? 0x80000000u : 0u)) : CODE32_ZERO;
             digits[(uint64_t)w * n + i] = code;
             w++;
         };
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_count(uint32_t *bin_counts
 #define BIN_ITEMS 8u           // items per thread; span = BIN_ITEMS * SORT_THREADS
 __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint32_t *val, const uint32_t *bin_starts, const uint32_t *codes,
                                                               uint64_t total, uint32_t nbins, uint32_t nblocks, uint32_t shift, uint32_t span, uint64_t n,
-                                                              uint32_t set_shift, uint32_t batch_n) {
+                                                              uint32_t set_shift, uint32_t batch_n, uint32_t tstride) {
     ZK_CHAIN_PRIO();
     extern __shared__ uint32_t smem[];
     uint32_t *cnt = smem;                         // [BIN_MAX] per-bin count, then LDS start
@@ -377,6 +379,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * span;
     const uint32_t lomask = (1u << shift) - 1u;
+    // tables with a row per `tstride` windows: item w * n + i reads row (w / tstride) * n + i.  The block's first window by one
+    // (uniform) division, the items' by comparison.
+    const uint64_t w_base = tstride > 1 ? base / n : 0, r_base = tstride > 1 ? base - w_base * n : 0;
     uint32_t code[BIN_ITEMS], rank[BIN_ITEMS];
 #pragma unroll
     for (uint32_t k = 0; k < BIN_ITEMS; k++) {
@@ -417,6 +422,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint
             // table row: the flattened index j*n + i itself with window-precomputed tables
             // (set_shift = 32), the point index i otherwise (key >> set_shift = window j)
             uint64_t i = base + (uint64_t)k * SORT_THREADS + tid - (uint64_t)(set_shift < 32 ? mag >> set_shift : 0u) * n;
+            if (tstride > 1) {
+                uint64_t w = w_base, r = r_base + (uint64_t)k * SORT_THREADS + tid;
+                while (r >= n) { r -= n; w++; }
+                i = (w / tstride) * n + r;
+            }
             if (batch_n) {          // batched vectors share the table: flattened j * n + (v * batch_n + r)  ->  row j * batch_n + r
                 const uint64_t j = i / n, r = (i % n) % batch_n;
                 i = j * batch_n + r;
@@ -1371,7 +1381,7 @@ void launch_msm_sort(const MsmSortBufs &b, const Fr *scalars, uint64_t n, MsmPla
     ZK_LAUNCH(k_bin_count, dim3(nblocks), dim3(SORT_THREADS), 0, s, b.bin_counts, (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span());
     launch_scan(b.bin_starts, b.bin_counts, nbins * nblocks, s);
     ZK_LAUNCH(k_bin_scatter, dim3(nblocks), dim3(SORT_THREADS), bin_scatter_lds_bytes(), s, b.lo, b.val, (const uint32_t *)b.bin_starts,
-                       (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span(), n, set_shift, p.batch > 1 ? p.batch_n : 0u);
+                       (const uint32_t *)b.codes, total, nbins, nblocks, sh, bin_span(), n, set_shift, p.batch > 1 ? p.batch_n : 0u, p.precomp);
     ZK_LAUNCH(k_bin_count_lds, dim3(grid2), dim3(SORT_THREADS), lds, s, b.counts, (const uint16_t *)b.lo,
                        (const uint32_t *)b.bin_starts, nblocks, bpb, nbins, slices, tb);
     launch_scan(b.starts, b.counts, tb * slices, s);
@@ -1438,8 +1448,13 @@ static void precomp_table(Affine<F> *table, XYZZ<F> *tmp, F *pref, uint64_t n, M
     ZK_LAUNCH(k_precomp_normalize<F>, dim3((uint32_t)((segs + 63) / 64)), dim3(64), 0, s, table + n, (const XYZZ<F> *)tmp, pref, total);
     ZK_LAUNCH_OK("window pre-computation");
 }
-void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq>(table, tmp, pref, n, p, s); }
-void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq2>(table, tmp, pref, n, p, s); }
+// (a table with a row per second window is a table with a row per window of twice the width)
+static MsmPlan table_plan(MsmPlan p) {
+    if (p.precomp > 1) { p.W = msm_table_rows(p); p.c *= p.precomp; }
+    return p;
+}
+void launch_msm_precomp_g1(G1Affine *table, G1XYZZ *tmp, Fq *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq>(table, tmp, pref, n, table_plan(p), s); }
+void launch_msm_precomp_g2(G2Affine *table, G2XYZZ *tmp, Fq2 *pref, uint64_t n, MsmPlan p, hipStream_t s) { precomp_table<Fq2>(table, tmp, pref, n, table_plan(p), s); }
 
 // workspace: level-1 slots (2 per lane) + level-2 slots + ... (geometric: < 2.2x level 1)
 static inline uint32_t accum_chunk_min() {

@@ -23,7 +23,7 @@ void alloc_slot(zk_prover *p, int i) {
     zk_prover::ProofSlot &q = p->slot[i];
     if (q.allocated) return;
     const uint64_t nv = p->sv.size();
-    q.sort_w.alloc(nv, p->wbits, p->precomp, p->batch);
+    q.sort_w.alloc(nv, p->wbits, p->table_mode, p->batch);
     const MsmPlan pw = q.sort_w.plan, ph = p->sort_h.plan;
     const uint64_t tbw = q.sort_w.total_buckets(), tbh = p->sort_h.total_buckets();
     q.buckets_g1.alloc(3 * tbw + tbh);
@@ -97,8 +97,9 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     p->shard_index = o ? o->shard_index : 0;
     p->batch = (o && o->batch > 1) ? o->batch : 1;
     if (p->batch > ZK_MAX_BATCH) throw std::invalid_argument("opts.batch > ZK_MAX_BATCH");
-    if (p->batch > 1 && (!(p->flags & ZK_FLAG_PRECOMP) || p->shard_count != 1 || (p->flags & ZK_FLAG_PARTITIONED_CHAIN)))
-        throw std::invalid_argument("opts.batch needs ZK_FLAG_PRECOMP on an unsharded prover");
+    if (p->flags & ZK_FLAG_PRECOMP_HALF) p->flags |= ZK_FLAG_PRECOMP;       // (a kind of pre-computation)
+    if (p->batch > 1 && (!(p->flags & ZK_FLAG_PRECOMP) || (p->flags & ZK_FLAG_PRECOMP_HALF) || p->shard_count != 1 || (p->flags & ZK_FLAG_PARTITIONED_CHAIN)))
+        throw std::invalid_argument("opts.batch needs ZK_FLAG_PRECOMP (a row per window) on an unsharded prover");
     if (p->shard_index >= p->shard_count) throw std::invalid_argument("shard_index >= shard_count");
     const uint32_t wbits = o ? o->window_bits : 0;
 
@@ -280,10 +281,12 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     // --- point tables: this shard's contiguous slices
     const uint64_t nv = p->sv.size(), nh = p->sh.size();
     p->precomp = (p->flags & ZK_FLAG_PRECOMP) != 0;
-    p->sort_h.alloc(nh, wbits, p->precomp, p->batch);
+    p->table_mode = (p->flags & ZK_FLAG_PRECOMP_HALF) ? 2u : p->precomp ? 1u : 0u;
+    p->sort_h.alloc(nh, wbits, p->table_mode, p->batch);
     alloc_slot(p.get(), 0);
-    // with window pre-computation a table holds W rows: row j = 2^(c*j) * P (msm.hip)
-    const uint64_t rows_w = p->precomp ? p->slot[0].sort_w.plan.W : 1, rows_h = p->precomp ? p->sort_h.plan.W : 1;
+    // with window pre-computation a table holds W rows: row j = 2^(c*j) * P (msm.hip) — or, with ZK_FLAG_PRECOMP_HALF, the
+    // ceil(W/2) rows of the even windows
+    const uint64_t rows_w = msm_table_rows(p->slot[0].sort_w.plan), rows_h = msm_table_rows(p->sort_h.plan);
     p->ptsA.alloc((nv ? nv : 1) * rows_w);
     p->ptsB1.alloc((nv ? nv : 1) * rows_w);
     p->ptsB2.alloc((nv ? nv : 1) * rows_w);
@@ -323,7 +326,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
     if (p->precomp) {
         // one scratch area for the doubling walks, reused table after table (freed on return)
         const MsmPlan plan_w = p->slot[0].sort_w.plan;
-        const uint64_t tw = (uint64_t)(plan_w.W - 1) * (nv ? nv : 1), th = (uint64_t)(p->sort_h.plan.W - 1) * (nh ? nh : 1);
+        const uint64_t tw = (uint64_t)(rows_w - 1) * (nv ? nv : 1), th = (uint64_t)(rows_h - 1) * (nh ? nh : 1);
         const uint64_t tmax = tw > th ? tw : th;
         DevBuf<G2XYZZ> tmp;
         DevBuf<Fq2> pref;
@@ -362,7 +365,7 @@ void prover_create(zk_prover **out, const zk_zkey_view *z, const zk_opts *o) {
             x->n_h = p->nloc * p->batch;
             x->nh_sort = nh;
             x->wbits = wbits;
-            x->precomp = p->precomp;
+            x->precomp = p->table_mode;
             x->batch = p->batch;
             p->extra[l - 1] = std::move(x);
         }
@@ -458,7 +461,9 @@ int zk_prover_info(zk_prover *p, zk_prover_plan *plan) {
         const MsmPlan ph = p->sort_h.plan, pw = p->slot[0].sort_w.plan;
         o.window_bits_h = ph.c; o.windows_h = ph.W;
         o.window_bits_w = pw.c; o.windows_w = pw.W;
-        o.precomputed_tables = p->precomp ? 1u : 0u;
+        o.precomputed_tables = p->table_mode;
+        o.table_rows_h = msm_table_rows(ph); o.table_rows_w = msm_table_rows(pw);
+        o.bucket_sets_h = ph.sets; o.bucket_sets_w = pw.sets;
         o.msm_a_b1_c_one_launch = p->batch_abc ? 1u : 0u;
         o.lanes = (uint32_t)p->lanes;
         o.follow_up_streams = (uint32_t)p->tail_streams;

@@ -134,13 +134,14 @@ struct SortBufs {
     uint32_t total_buckets() const { return plan.sets * plan.nbuckets; }
     uint64_t max_entries() const { return (n ? n : 1) * plan.W; }
     // batch > 1: `batch` scalar vectors of n_ scalars each, sorted together into one bucket set per vector
-    void alloc(uint64_t n_, uint32_t window_bits, bool precomp = false, uint32_t batch = 1) {
+    // precomp: 0 = tables as in the zkey, 1 = a table row per window, 2 = a row per second window (MsmPlan::precomp)
+    void alloc(uint64_t n_, uint32_t window_bits, uint32_t precomp = 0, uint32_t batch = 1) {
         plan = make_msm_plan(n_ ? n_ : 1, window_bits, precomp, batch);
         n = n_ * (batch > 1 ? batch : 1);
         // sort entries are 32-bit (bit 31 = digit sign): positions n*W and, with window-precomputed
         // tables, table rows j*n + i must stay below 2^32 / 2^31
         if ((n ? n : 1) * plan.W >= (1ull << 32)) throw std::invalid_argument("MSM too large: n * windows >= 2^32 sort entries");
-        if ((n ? n : 1) * (precomp ? plan.W : 1) >= (1ull << 31)) throw std::invalid_argument("MSM too large: table rows >= 2^31");
+        if ((n ? n : 1) * msm_table_rows(plan) >= (1ull << 31)) throw std::invalid_argument("MSM too large: table rows >= 2^31");
         MsmSortSizes z = msm_sort_sizes(n, plan);
         lo.alloc(z.lo_u16);
         counts.alloc(z.counts_u32);
@@ -202,7 +203,8 @@ struct zk_prover {
     NttPair pair;               // nttpair.hip: tables of the coset-evaluation pipeline for this prover's block (pair.L == 0: not used)
     Slice sv, sh;              // this shard's slice of witness indices / domain indices
     uint32_t c_idx_min = 0;    // C-MSM: local witness index >= c_idx_min maps to pointsC[idx - c_idx_min]
-    bool precomp = false;      // window-precomputed tables (ZK_FLAG_PRECOMP): tables hold W rows of n points
+    bool precomp = false;      // window-precomputed tables (ZK_FLAG_PRECOMP): tables hold W rows of n points ...
+    uint32_t table_mode = 0;   // ... (1), or ceil(W/2) rows with ZK_FLAG_PRECOMP_HALF (2); 0 = tables as in the zkey.  What SortBufs::alloc takes.
     DevBuf<G1Affine> ptsA, ptsB1, ptsC, ptsH;
     DevBuf<G2Affine> ptsB2;
 
@@ -310,7 +312,8 @@ struct zk_prover {
         // use more than lane 0
         uint64_t n_abc = 0, n_h = 0, nh_sort = 0;
         uint32_t wbits = 0, batch = 1;
-        bool precomp = false, one_stream = false;
+        uint32_t precomp = 0;       // the prover's table_mode
+        bool one_stream = false;
         bool ready = false;         // set at the END of ensure(), like ProofSlot::allocated: a call that ran out of memory half-way
                                     // (six proofs in flight at 2^22 next to nearly full tables) is repeated by the next proof on the
                                     // lane instead of leaving h / sort_h null behind a non-null abc

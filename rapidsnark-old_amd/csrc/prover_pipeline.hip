@@ -701,7 +701,7 @@ void zkp::collect_sums(zk_prover *p, zk_msm_sums *out, SubmittedRS *rs, const Di
             throw std::runtime_error("getrandom failed");
         return;
     }
-    if (Ww == 1 && Wh == 1) {          // window-precomputed tables: one sum per MSM, nothing to run in parallel
+    if (Ww <= 2 && Wh <= 2) {          // window-precomputed tables: one sum per MSM (two with rows for every second window), nothing to run in parallel
         HostTail::combine_windows_g1(w1, Ww, cw, rcw, out->pi_a);
         HostTail::combine_windows_g1(w1 + M1, Ww, cw, rcw, out->pib1);
         HostTail::combine_windows_g1(w1 + 2 * M1, Ww, cw, rcw, out->pi_c);

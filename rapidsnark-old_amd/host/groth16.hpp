@@ -146,10 +146,12 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
     }
     zk_opts o{};
     o.device = -1;
-    // ZKHIP_PRECOMP=1/0: window-precomputed tables (W x table memory, longer create, ~10 % faster
-    // proofs).  Default: off for the one-shot CLI, on for the server where create is amortised.
+    // ZKHIP_PRECOMP=1/2/0: window-precomputed tables (W x table memory, longer create, ~13 % faster proofs); 2: rows for every
+    // second window only (ceil(W/2) x the memory, same additions per point, two bucket reductions per MSM: ZK_FLAG_PRECOMP_HALF).
+    // Default: off for the one-shot CLI, on for the server where create is amortised.
     const char *pc = getenv("ZKHIP_PRECOMP");
-    if (pc ? (pc[0] == '1') : precompDefault) o.flags |= ZK_FLAG_PRECOMP;
+    if (pc ? (pc[0] == '1' || pc[0] == '2') : precompDefault) o.flags |= ZK_FLAG_PRECOMP;
+    if (pc && pc[0] == '2') o.flags |= ZK_FLAG_PRECOMP_HALF;
     // ZKHIP_SPARSE_WITNESS=1 (with precomputed tables): 16-bit window for the four witness MSMs — for deployments whose witnesses
     // are circuit witnesses (mostly 0, 1 and small values), ZK_FLAG_SPARSE_WITNESS in include/zkhip.h
     if (const char *sw = getenv("ZKHIP_SPARSE_WITNESS"))
@@ -205,9 +207,17 @@ inline std::unique_ptr<Prover> makeProver(uint32_t nVars, uint32_t nPublic, uint
         return rc;
     };
     int rc = create(reserveInFlight);
-    // window-precomputed tables are 13 x the table memory (2^26 constraints: > 288 GB): where they were only the DEFAULT
-    // (proverServer) and they, or the workspace of even two proofs beside them, do not fit, the prover is created with the
-    // tables as they are in the zkey instead of not at all
+    // window-precomputed tables are 13 x the table memory (2^25 constraints: 167 GB + workspace; 2^26: > 288 GB): where they
+    // were only the DEFAULT (proverServer, or a server that already holds other keys) and they, or the workspace of even two
+    // proofs beside them, do not fit: first the rows of every second window (7 x, the same 13 additions per point) ...
+    if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !(o.flags & ZK_FLAG_PRECOMP_HALF) && !pc && oom()) {
+        std::cerr << "window-precomputed tables do not fit the GPU's free memory: rows for every second window\n";
+        o.flags |= ZK_FLAG_PRECOMP_HALF;
+        o.batch = 0;                               // (batched submissions need a row per window)
+        rc = create(reserveInFlight);
+        if (rc != 0) o.flags &= ~(uint32_t)ZK_FLAG_PRECOMP_HALF;
+    }
+    // ... then the tables as they are in the zkey instead of no prover at all
     if (rc != 0 && (o.flags & ZK_FLAG_PRECOMP) && !pc && oom()) {
         std::cerr << "window-precomputed tables do not fit the GPU's free memory: using the tables as in the zkey\n";
         o.flags &= ~(uint32_t)ZK_FLAG_PRECOMP;

@@ -48,7 +48,8 @@ class zk_prover_plan(C.Structure):
                 ("follow_up_streams", C.c_uint32), ("max_in_flight", C.c_uint32), ("depth_host_witness", C.c_uint32),
                 ("depth_resident_witness", C.c_uint32), ("batch", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
                 ("chain_partitioned", C.c_uint32), ("device_bytes_in_use", C.c_uint64), ("device_bytes_total", C.c_uint64),
-                ("kernel_launches_last_proof", C.c_uint64)]
+                ("kernel_launches_last_proof", C.c_uint64), ("table_rows_h", C.c_uint32), ("table_rows_w", C.c_uint32),
+                ("bucket_sets_h", C.c_uint32), ("bucket_sets_w", C.c_uint32)]
 
 
 def prover_info(lib, handle):
@@ -63,6 +64,16 @@ ZK_FLAG_TIMINGS = 1
 ZK_FLAG_PRECOMP = 2
 ZK_FLAG_PARTITIONED_CHAIN = 4
 ZK_FLAG_SPARSE_WITNESS = 8
+ZK_FLAG_PRECOMP_HALF = 16
+
+
+def precomp_flags(precomp):
+    """The `precomp` option of the bindings -> ZK_FLAG_*: False / 0 = tables as in the zkey, True / 1 = a table row per
+    window (ZK_FLAG_PRECOMP), 2 = a row per second window (ZK_FLAG_PRECOMP_HALF: 7 instead of 13 x the table memory)."""
+    mode = int(precomp)
+    if mode not in (0, 1, 2):
+        raise ValueError("precomp: 0, 1 or 2")
+    return (0, ZK_FLAG_PRECOMP, ZK_FLAG_PRECOMP | ZK_FLAG_PRECOMP_HALF)[mode]
 ZK_STEP_CROSS_INVERSE, ZK_STEP_LOCAL, ZK_STEP_CROSS_FORWARD, ZK_STEP_FINISH = 1, 2, 3, 4
 ZK_T_NAMES = ["spmv", "ntt_chain_wall", "sort_h", "msm_h_wall", "join_wait", "msm_reduce", "total_device", "g1_l1_kernel", "g2_l1_kernel", "wtns_h2d"]
 

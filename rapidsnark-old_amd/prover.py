@@ -45,7 +45,7 @@ class Prover:
         self._keep = []
         self.header, v = _zkey_view(zkey, self._keep)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
-                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
+                      (L.ZK_FLAG_TIMINGS if timings else 0) | L.precomp_flags(precomp)
                       | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0), batch)
         self._h = C.c_void_p()
         L.check(self._lib.zk_prover_create(C.byref(self._h), C.byref(v), C.byref(o)))
@@ -195,7 +195,7 @@ class MultiProver:
         keep = []
         self.header, v = _zkey_view(zkey, keep)
         devs = (C.c_int32 * len(devices))(*devices)
-        o = L.zk_opts(-1, 0, 1, window_bits, L.ZK_FLAG_PRECOMP if precomp else 0)
+        o = L.zk_opts(-1, 0, 1, window_bits, L.precomp_flags(precomp))
         self._h = C.c_void_p()
         L.check(self._lib.zk_multi_prover_create(C.byref(self._h), C.byref(v), devs, len(devices), C.byref(o)))
         ns, part = C.c_uint32(), C.c_uint32()

@@ -29,7 +29,7 @@ class MultiProverFromView:
         self.L, self.C, self.lib = L, C, L.load_library()
         v, keep = view_from_workload(L, wl)
         devs = (C.c_int32 * len(devices))(*devices)
-        o = L.zk_opts(-1, 0, 1, 0, L.ZK_FLAG_PRECOMP if precomp else 0)
+        o = L.zk_opts(-1, 0, 1, 0, L.precomp_flags(precomp))
         self.h = C.c_void_p()
         L.check(self.lib.zk_multi_prover_create(C.byref(self.h), C.byref(v), devs, len(devices), C.byref(o)))
         ns, part = C.c_uint32(), C.c_uint32()
@@ -59,7 +59,7 @@ class ProverFromView:
         self.lib = L.load_library()
         v, self.keep = view_from_workload(L, wl)
         o = L.zk_opts(device, shard_index, shard_count, window_bits,
-                      (L.ZK_FLAG_TIMINGS if timings else 0) | (L.ZK_FLAG_PRECOMP if precomp else 0)
+                      (L.ZK_FLAG_TIMINGS if timings else 0) | L.precomp_flags(precomp)
                       | (L.ZK_FLAG_PARTITIONED_CHAIN if partitioned_chain else 0) | (L.ZK_FLAG_SPARSE_WITNESS if sparse_witness else 0), batch)
         self.h = C.c_void_p()
         L.check(self.lib.zk_prover_create(C.byref(self.h), C.byref(v), C.byref(o)))

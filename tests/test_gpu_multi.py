@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name", ["r1cs_n64", "r1cs_n256"])
 @pytest.mark.parametrize("shards", [2, 3, 4, 8])
-@pytest.mark.parametrize("precomp", [False, True])
+@pytest.mark.parametrize("precomp", [False, True, 2])
 def test_multi_prover_equals_golden(zk, name, shards, precomp):
     """zk_multi_prove: 2/4/8 shards partition the chain (cross stages of 1/2/3 index bits), 3 shards fall
     back to the replicated chain; same proof bytes either way."""

@@ -61,7 +61,7 @@ def test_full_size_2p22_dlog_identities(zk):
     a, b, c = synth.expected_proof_dlogs(wl, dl, r, s)
     want = co.g1_mul(G1B, a) + co.g2_mul(G2B, b) + co.g1_mul(G1B, c)
     wd = torch.from_numpy(w).to("cuda:0")
-    for precomp in (False, True):
+    for precomp in (False, True, 2):         # 2: rows for every second window (7 x the tables, two sets of 2^19 buckets)
         p = _prover(zk, wl, precomp=precomp)
         _check_sums(p.prove_msm_dev(wd.data_ptr()), dl)
         assert p.prove_dev(wd.data_ptr(), r, s) == want

@@ -164,6 +164,11 @@ def test_precomp_mode_matches_plain_mode(zk, k, wbits):
         wd = torch.from_numpy(w).to("cuda:0")
         base = _prover(zk, wl).prove_msm_dev(wd.data_ptr())
         assert _prover(zk, wl, precomp=True, window_bits=wbits).prove_msm_dev(wd.data_ptr()) == base
+        # rows for every second window (ZK_FLAG_PRECOMP_HALF): odd windows add the neighbouring row into a second bucket set
+        half = _prover(zk, wl, precomp=2, window_bits=wbits)
+        assert half.prove_msm_dev(wd.data_ptr()) == base
+        plan = half.info()
+        assert plan["precomputed_tables"] == 2 and plan["bucket_sets_h"] == 2 and plan["table_rows_h"] == (plan["windows_h"] + 1) // 2
 
 
 def test_fixed_base_batch_matches_host_scalar_mul(zk):
@@ -211,7 +216,7 @@ def test_valid_key_at_scale_passes_trapdoor_check(zk, tmp_path, k, precomp):
 
 
 @pytest.mark.parametrize("k,n_vars,n_public", [(13, 5000, 7), (13, 8191, 1), (13, 12345, 40), (12, 4097, 0), (14, 16384 + 4096, 2)])
-@pytest.mark.parametrize("precomp", [False, True])
+@pytest.mark.parametrize("precomp", [False, True, 2])
 def test_irregular_shapes_bit_exact_vs_c_oracle(zk, k, n_vars, n_public, precomp):
     """Real circuits have nVars != domainSize and several public signals; the synthetic family has nVars = domainSize and
     one.  Mid-size keys with fewer / more signals than domain rows, nPublic from 0 to 40, odd table lengths: the GPU
@@ -241,7 +246,7 @@ def test_irregular_shapes_bit_exact_vs_c_oracle(zk, k, n_vars, n_public, precomp
     p.lib.zk_prover_destroy(p.h)
 
 
-@pytest.mark.parametrize("precomp", [False, True])
+@pytest.mark.parametrize("precomp", [False, True, 2])
 def test_circuit_shaped_key_bit_exact_vs_c_oracle(zk, precomp):
     """The circuit-shaped member of the family (synth.workload(shape="circuit"): nVars = 3/4 of the domain + 5, three public
     signals, ~30 % of the rows of A and of B1 / B2 at infinity) with the 80/15/5 witness — what bench.py's `also_realistic`
@@ -292,7 +297,7 @@ def test_sparse_witness_flag_changes_the_window_not_the_sums(zk):
     assert used[1] > used[0] * 1.02, used          # 16 rows per point for A, B1, B2, C instead of 14 (the bucket arrays shrink: +3.6 % in all)
 
 
-@pytest.mark.parametrize("precomp", [False, True])
+@pytest.mark.parametrize("precomp", [False, True, 2])
 def test_proofs_submitted_beside_others_bit_exact_vs_c_oracle(zk, precomp):
     """From 2^17 a proof submitted while another one is in flight runs fewer, longer level-1 lanes (at least 128 entries each, one
     round of lanes up to 1280: csrc/prover_pipeline.hip, "entries per level-1 lane") — another cut of the bucket runs, the same sums.
