@@ -556,6 +556,7 @@ def shard8_leg(zk, torch, wl, k, w_dev, single_ms, single_lone_ms, precomp, rank
             p.collect_msm()
         launches = p.info()["kernel_launches_last_proof"]
         torch.cuda.synchronize()
+        leg_marker(zk, torch, "2p%d_shard8_one_at_a_time" % k)      # (tools/profile_bench.sh: a kernel table per mode of this leg)
         n1 = 8
         t0 = time.perf_counter()
         for _ in range(n1):
@@ -563,6 +564,7 @@ def shard8_leg(zk, torch, wl, k, w_dev, single_ms, single_lone_ms, precomp, rank
             p.collect_msm()
         one = (time.perf_counter() - t0) / n1 * 1e3
         stage = {a: round(b, 3) for a, b in p.timings().items()}
+        leg_marker(zk, torch, "2p%d_shard8_two_in_flight" % k)
         n2 = 12
         submit()
         t0 = time.perf_counter()
@@ -571,6 +573,7 @@ def shard8_leg(zk, torch, wl, k, w_dev, single_ms, single_lone_ms, precomp, rank
             p.collect_msm()
         p.collect_msm()
         two = (time.perf_counter() - t0) / (n2 + 1) * 1e3
+        leg_marker(zk, torch, "2p%d_shard8_after" % k)
         launches_busy = p.info()["kernel_launches_last_proof"]
     finally:
         p.lib.zk_prover_destroy(p.h)
