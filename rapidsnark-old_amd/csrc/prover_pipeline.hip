@@ -235,9 +235,13 @@ static void enqueue_witness_msms(zk_prover *p, PhaseCtx &c) {
     // at the very end.  The merges and the bucket reduction of MSM B2 go there instead of standing in stream 2's line: the
     // A|B1|C launch starts right behind the G2 level-1 launch, and the G2 reduction no longer ends the proof.  Medians of 16
     // synchronous proofs, three alternations (profiles/r04an_g2_aside_medians.txt): 2^14 1.61 -> 1.37 ms, 2^16 2.31 -> 1.88,
-    // 2^17 2.98 -> 2.58, 2^18 4.46 -> 4.18, 2^19 7.52 -> 7.35; at 2^22 it LOSES 0.2-2 ms (r04am: the merges then run beside the
-    // chip-filling A|B1|C launch, which they slow down more than their own 0.5 ms), hence the size limit.
-    static const uint32_t g2_aside_maxlog = [] { const char *e = probe_env("ZKHIP_G2_ASIDE_MAXLOG"); return e ? (uint32_t)atoi(e) : 19u; }();
+    // 2^17 2.98 -> 2.58, 2^18 4.46 -> 4.18, 2^19 7.52 -> 7.35; at 2^22 it LOST 0.2-2 ms in round 4 (r04am: the merges then run beside the
+    // chip-filling A|B1|C launch, which they slow down more than their own 0.5 ms), hence a size limit.  Round 6, with the wave
+    // priorities and the split reduction in place (same box, three alternations, one proof at a time with a resident witness /
+    // synchronous with a host witness, profiles/r06g_*, r06h_*): 2^20 10.71 / 10.61 / 10.62 -> 10.01 / 9.93 / 9.90 ms (the G2 reduction
+    // was the LAST kernel chain of such a proof: 1.0 ms behind MSM A and B1 on stream 2), 2^21 17.85 / 18.38 / 18.00 -> 17.12 / 16.95 /
+    // 16.94; 2^22 and 2^24 equal within the noise (32.87 vs 32.75, 124.5 vs 123.8); pipelined periods unchanged everywhere: limit 2^21.
+    static const uint32_t g2_aside_maxlog = [] { const char *e = probe_env("ZKHIP_G2_ASIDE_MAXLOG"); return e ? (uint32_t)atoi(e) : 21u; }();
     const bool g2_aside = !tails && c.sf != s2 && c.sf != c.s && p->in_flight == 0 && !p->capturing && !p->use_graph &&
                           p->sv.size() <= ((uint64_t)1 << g2_aside_maxlog);      // (the witness slice: a shard of a large proof is a small MSM)
     // (The WHOLE MSM B2 there, its level-1 launch beside the A|B1|C one, was measured too: nothing at 2^14 ... 2^16, +4-7 % at
