@@ -113,7 +113,8 @@ def test_cli_over_several_devices(tmp_path, devices):
 # Every environment variable INTEGRATION.md section 5 documents for the library / CLI, with a non-default value: none of them
 # may change the proof.  The retired measurement probes (compiled out of the shipped library: -DZK_PROBES) are set too —
 # ZKHIP_GATHER_MASK used to give WRONG proofs with exit code 0; in the default build it must have no effect at all.
-_DOCUMENTED = [{"ZKHIP_VERBOSE": "1"}, {"ZKHIP_SERIAL": "1"}, {"ZKHIP_PRECOMP": "1"}, {"ZKHIP_PRECOMP": "0"}, {"ZKHIP_DEVICE": "0"},
+_DOCUMENTED = [{"ZKHIP_VERBOSE": "1"}, {"ZKHIP_SERIAL": "1"}, {"ZKHIP_PRECOMP": "1"}, {"ZKHIP_PRECOMP": "0"}, {"ZKHIP_PRECOMP": "2"},
+               {"ZKHIP_PRECOMP": "2", "ZKHIP_DEVICES": "0,0"}, {"ZKHIP_DEVICE": "0"},
                {"ZKHIP_LANES": "1"}, {"ZKHIP_LANES": "3", "ZKHIP_LANE_STREAMS": "1"}, {"ZKHIP_TAIL": "0"}, {"ZKHIP_TAIL": "2"},
                {"ZKHIP_GRAPH": "1"}, {"ZKHIP_BATCH_ABC": "0"}, {"ZKHIP_BATCH_ABC": "1", "ZKHIP_PRECOMP": "1"},
                {"ZKHIP_DEVICES": "0,0,0,0", "ZKHIP_REPLICATED_CHAIN": "1"}, {"GPU_MAX_HW_QUEUES": "8"}, {"ZKHIP_CLEAN_EXIT": "1"},
