@@ -381,7 +381,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint
     const uint32_t lomask = (1u << shift) - 1u;
     // tables with a row per `tstride` windows: item w * n + i reads row (w / tstride) * n + i.  The block's first window by one
     // (uniform) division, the items' by comparison.
-    const uint64_t w_base = tstride > 1 ? base / n : 0, r_base = tstride > 1 ? base - w_base * n : 0;
+    const uint64_t w_base = tstride > 1 && n ? base / n : 0, r_base = tstride > 1 && n ? base - w_base * n : 0;      // (n = 0: an empty shard — no item is used)
     uint32_t code[BIN_ITEMS], rank[BIN_ITEMS];
 #pragma unroll
     for (uint32_t k = 0; k < BIN_ITEMS; k++) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bin_scatter(uint16_t *lo, uint
             uint64_t i = base + (uint64_t)k * SORT_THREADS + tid - (uint64_t)(set_shift < 32 ? mag >> set_shift : 0u) * n;
             if (tstride > 1) {
                 uint64_t w = w_base, r = r_base + (uint64_t)k * SORT_THREADS + tid;
-                while (r >= n) { r -= n; w++; }
+                while (n && r >= n) { r -= n; w++; }
                 i = (w / tstride) * n + r;
             }
             if (batch_n) {          // batched vectors share the table: flattened j * n + (v * batch_n + r)  ->  row j * batch_n + r
