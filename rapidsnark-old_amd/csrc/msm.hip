@@ -46,8 +46,11 @@ MsmPlan make_msm_plan(uint64_t n, uint32_t window_bits, uint32_t precomp, uint32
                                       // 2^16 .. 2^19 measured neutral or worse with a wider window)
             if (lg == 21) c = 20;     // 13 instead of 14: pays since the split bucket reduction (17.0 -> 16.55 ms, profiles/r05ze_window_sweep.txt)
             if (batch > 1) c++;       // a batch shares the fixed costs of a set of launches: one window fewer pays (2^16 x 8: 0.76 -> 0.69 ms per proof)
+            if (c > 20) c = 20;       // the size-based choice stops at 2^19 buckets per set: a 22-bit window (12 additions per point) was measured at
+                                      // 2^24, where the reductions are cheapest — see the cap below
         }
-        if (c > 20) c = 20;
+        if (c > 22) c = 22;           // an explicit width may go to 22 (2^21 buckets per set: 8192-bucket bins in the sort's second level, 64-bucket
+                                      // lanes in the split reduction; parity-tested) — it does not pay: profiles/r06t_ab_window_22_at_2p24.txt
     } else {
         if (c == 0) c = lg > 6 ? lg - 6 : 2;     // ~128 points per bucket on random scalars
         if (c > 16) c = 16;                      // one window's histogram must fit one CU's LDS
@@ -1276,7 +1279,8 @@ static inline uint32_t reduce_split_top(uint32_t L) {
 static inline uint32_t reduce_split_for(MsmPlan p) {
     static const int forced = [] { const char *e = probe_env("ZKHIP_REDUCE_SPLIT"); return e ? atoi(e) : -1; }();
     if (reduce_bits_for(p) || p.nbuckets < (1u << 14)) return 0;
-    const uint32_t ch = forced >= 0 ? (uint32_t)forced : REDUCE_SPLIT;
+    // (sets of more than 2^19 buckets: longer lanes, so that the T level stays the 2^15 points the last two launches are sized for)
+    const uint32_t ch = forced >= 0 ? (uint32_t)forced : (p.nbuckets > (REDUCE_SPLIT << 15) ? p.nbuckets >> 15 : REDUCE_SPLIT);
     if (ch < 2 || (ch & (ch - 1)) != 0 || ch > p.nbuckets) return 0;
     // the last two launches take the shares and the A level together (k_msm_reduce_final2): whole tree workgroups of
     // shares, and at most one final half of partial sums, for both fan-ins
