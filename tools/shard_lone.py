@@ -2,7 +2,7 @@
 (tools/lone_timeline.py cuts clusters at 30 ms of silence):
     python tools/shard_lone.py [log2n=22] [G=8] [proofs=4] [in_flight=1]
 Rank 0's share with the chain partitioned and the all_to_all left out, exactly as tools/shard_probe.py runs it.
-in_flight=2: no pauses, `proofs` shares with two in flight (the kernel table of a rank's steady state: rocprofv3 --kernel-trace --stats)."""
+in_flight=N >= 2: no pauses, `proofs` shares with N in flight (the kernel table of a rank's steady state: rocprofv3 --kernel-trace --stats)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -23,13 +23,15 @@ ch = ShardedChain(p.lib, p.h, None, torch.device("cuda:0"), exchange=lambda dst,
 for i in range(3):
     ch.submit(d_wtns=w.data_ptr()); p.collect_msm()
 torch.cuda.synchronize()
-if inflight == 2:
-    ch.submit(d_wtns=w.data_ptr())
+if inflight >= 2:
+    for _ in range(inflight - 1):
+        ch.submit(d_wtns=w.data_ptr())
     t0 = time.perf_counter()
     for i in range(reps):
         ch.submit(d_wtns=w.data_ptr()); p.collect_msm()
-    p.collect_msm()
-    print("share of 2^%d / %d, two in flight: %.2f ms each (%d + 1 shares)" % (k, G, (time.perf_counter() - t0) / (reps + 1) * 1e3, reps), flush=True)
+    for _ in range(inflight - 1):
+        p.collect_msm()
+    print("share of 2^%d / %d, %d in flight: %.2f ms each (%d + %d shares)" % (k, G, inflight, (time.perf_counter() - t0) / (reps + inflight - 1) * 1e3, reps, inflight - 1), flush=True)
     sys.exit(0)
 for i in range(reps):
     time.sleep(0.06)
