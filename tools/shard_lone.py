@@ -32,6 +32,8 @@ if inflight >= 2:
     for _ in range(inflight - 1):
         p.collect_msm()
     print("share of 2^%d / %d, %d in flight: %.2f ms each (%d + %d shares)" % (k, G, inflight, (time.perf_counter() - t0) / (reps + inflight - 1) * 1e3, reps, inflight - 1), flush=True)
+    p.lib.zk_prover_destroy(p.h)
+    torch.cuda.synchronize()
     sys.exit(0)
 for i in range(reps):
     time.sleep(0.06)
